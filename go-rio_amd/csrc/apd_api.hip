@@ -1,0 +1,784 @@
+// apd_api.hip -- host side of the APD-GICP C ABI declared in include/gorio_apd.h.
+//
+// One gorio_apd handle == one fast_gicp::FastAPDGICP object (APDH:20-122): it owns the device copies of the two clouds,
+// their covariances, the per-source-point correspondence state and the device-resident optimiser state, and it drives
+// the kernels of apd_kernels.hip.  No CPU compute path exists here: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gorio_apd.h"
+#include "apd_kernels.hip"
+
+using namespace gorio;
+
+namespace {
+
+constexpr int kPad = 16;
+constexpr float kFar = 1e30f;
+
+struct DevCloud {
+  float *x = nullptr, *y = nullptr, *z = nullptr, *label = nullptr;
+  double *cov6 = nullptr, *geo_w = nullptr;
+  int* knn = nullptr;      // [n][k] neighbour indices of the last covariance computation (parity hook)
+  float* part_d = nullptr; // k-NN partial lists
+  int* part_i = nullptr;
+  size_t part_cap = 0;     // elements
+  int knn_k = 0;
+  int n = 0, n_pad = 0, cap = 0;
+  bool present = false;
+  int cov_count = 0;       // == source_covs_.size(): n when valid, 0 when stale
+  CloudView view() const { return CloudView{x, y, z, label, cov6, geo_w, n, n_pad}; }
+};
+
+}  // namespace
+
+struct gorio_apd {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  gorio_apd_params params;
+  DevCloud src, tgt;
+  // per-source-point state
+  unsigned long long* best_key = nullptr;
+  int* corr = nullptr;
+  float* sqd = nullptr;
+  double* omega6 = nullptr;
+  double* partials = nullptr;
+  int pt_cap = 0;
+  bool corr_valid = false;
+  PairState* d_state = nullptr;
+  PairDesc* d_desc = nullptr;   // batch descriptor array (owned by the handle that leads a batch)
+  int desc_cap = 0;
+  PairState* d_states_batch = nullptr;
+  KnnJob* d_jobs = nullptr;
+  int jobs_cap = 0;
+  double* d_fit = nullptr;
+  std::string err;
+  // profiling
+  bool profiling = false;
+  double stage_s[4] = {0, 0, 0, 0};
+  int stage_n[4] = {0, 0, 0, 0};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(gorio_apd* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                                        \
+  do {                                                                                                          \
+    hipError_t e_ = (expr);                                                                                     \
+    if (e_ != hipSuccess) return fail(h, GORIO_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+void free_cloud(DevCloud& c) {
+  hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn); hipFree(c.part_d); hipFree(c.part_i);
+  c = DevCloud();
+}
+
+int ensure_cloud(gorio_apd* h, DevCloud& c, int n) {
+  const int n_pad = roundup(n, kPad) + kPad;
+  if (n_pad > c.cap) {
+    hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn);
+    c.x = c.y = c.z = c.label = nullptr; c.cov6 = c.geo_w = nullptr; c.knn = nullptr; c.knn_k = 0;
+    const int cap = n_pad + n_pad / 8;
+    HIP_TRY(h, hipMalloc(&c.x, sizeof(float) * cap));
+    HIP_TRY(h, hipMalloc(&c.y, sizeof(float) * cap));
+    HIP_TRY(h, hipMalloc(&c.z, sizeof(float) * cap));
+    HIP_TRY(h, hipMalloc(&c.label, sizeof(float) * cap));
+    HIP_TRY(h, hipMalloc(&c.cov6, sizeof(double) * 6 * cap));
+    HIP_TRY(h, hipMalloc(&c.geo_w, sizeof(double) * cap));
+    c.cap = cap;
+  }
+  c.n = n;
+  c.n_pad = n_pad;
+  return GORIO_OK;
+}
+
+int ensure_points(gorio_apd* h, int n) {
+  if (n > h->pt_cap) {
+    hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
+    h->best_key = nullptr; h->corr = nullptr; h->sqd = nullptr; h->omega6 = nullptr; h->partials = nullptr;
+    const int cap = n + n / 8 + 256;
+    HIP_TRY(h, hipMalloc(&h->best_key, sizeof(unsigned long long) * cap));
+    HIP_TRY(h, hipMalloc(&h->corr, sizeof(int) * cap));
+    HIP_TRY(h, hipMalloc(&h->sqd, sizeof(float) * cap));
+    HIP_TRY(h, hipMalloc(&h->omega6, sizeof(double) * 6 * cap));
+    HIP_TRY(h, hipMalloc(&h->partials, sizeof(double) * 28 * (cap / 256 + 2)));
+    h->pt_cap = cap;
+  }
+  return GORIO_OK;
+}
+
+// host strided AoS -> device SoA (+ padding)
+int upload_cloud(gorio_apd* h, DevCloud& c, const float* xyz, const float* label, int n, int stride_bytes) {
+  if (!xyz || n <= 0 || stride_bytes < 12 || (stride_bytes % 4) != 0) return fail(h, GORIO_ERR_INVALID, "set_input: bad cloud arguments");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = ensure_cloud(h, c, n);
+  if (rc) return rc;
+  const int np = c.n_pad;
+  std::vector<float> buf((size_t)np * 4);
+  float *bx = buf.data(), *by = bx + np, *bz = by + np, *bl = bz + np;
+  const int st = stride_bytes / 4;
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + (size_t)i * st;
+    bx[i] = p[0]; by[i] = p[1]; bz[i] = p[2];
+    bl[i] = label ? label[(size_t)i * st] : 0.0f;
+  }
+  for (int i = n; i < np; ++i) { bx[i] = kFar; by[i] = kFar; bz[i] = kFar; bl[i] = 0.0f; }
+  HIP_TRY(h, hipMemcpyAsync(c.x, bx, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(c.y, by, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(c.z, bz, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(c.label, bl, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  c.present = true;
+  c.cov_count = 0;
+  return GORIO_OK;
+}
+
+__global__ void fill_pad_kernel(float* x, float* y, float* z, float* label, int n, int n_pad, int has_label) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_pad) {
+    if (i >= n) { x[i] = 1e30f; y[i] = 1e30f; z[i] = 1e30f; label[i] = 0.0f; }
+    else if (!has_label) label[i] = 0.0f;
+  }
+}
+
+int upload_cloud_device(gorio_apd* h, DevCloud& c, const float* dx, const float* dy, const float* dz, const float* dl, int n) {
+  if (!dx || !dy || !dz || n <= 0) return fail(h, GORIO_ERR_INVALID, "set_input_device: bad cloud arguments");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = ensure_cloud(h, c, n);
+  if (rc) return rc;
+  HIP_TRY(h, hipMemcpyAsync(c.x, dx, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(c.y, dy, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(c.z, dz, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
+  if (dl) HIP_TRY(h, hipMemcpyAsync(c.label, dl, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
+  fill_pad_kernel<<<(c.n_pad + 255) / 256, 256, 0, h->stream>>>(c.x, c.y, c.z, c.label, n, c.n_pad, dl ? 1 : 0);
+  HIP_TRY(h, hipGetLastError());
+  c.present = true;
+  c.cov_count = 0;
+  return GORIO_OK;
+}
+
+ApdConsts make_consts(const gorio_apd_params& p) {
+  ApdConsts c;
+  c.thr2 = p.corr_dist_threshold * p.corr_dist_threshold;
+  c.dist_var = p.dist_var;
+  c.sin_az = std::sin(p.azimuth_var / 180 * M_PI);
+  c.sin_el = std::sin(p.elevation_var / 180 * M_PI);
+  c.rot_eps = p.rotation_epsilon;
+  c.trans_eps = p.transformation_epsilon;
+  c.lm_init_lambda_factor = p.lm_init_lambda_factor;
+  c.inv_n_scale = 1.0;
+  c.optimizer = p.optimizer;
+  c.lm_max_iterations = p.lm_max_iterations;
+  c.max_iterations = p.max_iterations;
+  c.pad_ = 0;
+  return c;
+}
+
+struct StageTimer {
+  gorio_apd* h;
+  int stage;
+  bool on;
+  StageTimer(gorio_apd* h_, int s) : h(h_), stage(s), on(h_->profiling) {
+    if (on) hipEventRecord(h->ev0, h->stream);
+  }
+  ~StageTimer() {
+    if (on) {
+      hipEventRecord(h->ev1, h->stream);
+      hipEventSynchronize(h->ev1);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, h->ev0, h->ev1);
+      h->stage_s[stage] += ms * 1e-3;
+      h->stage_n[stage] += 1;
+    }
+  }
+};
+
+// covariance estimation for a list of clouds on lead's stream
+int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*>>& todo) {
+  if (todo.empty()) return GORIO_OK;
+  const int njobs = (int)todo.size();
+  const int k = lead->params.k_correspondences;
+  const int K = k <= 20 ? 20 : 32;
+  long total_waves = 0;
+  int max_n = 0;
+  for (auto& t : todo) {
+    total_waves += (t.second->n + 63) / 64;
+    if (t.second->n > max_n) max_n = t.second->n;
+  }
+  int splits = (int)((8192 + total_waves - 1) / total_waves);
+  if (splits < 1) splits = 1;
+  if (splits > 32) splits = 32;
+  std::vector<KnnJob> jobs(njobs);
+  int max_splits = 1;
+  for (int q = 0; q < njobs; ++q) {
+    gorio_apd* h = todo[q].first;
+    DevCloud& c = *todo[q].second;
+    int chunk = roundup((c.n_pad + splits - 1) / splits, kPad);
+    if (chunk < 256) chunk = 256;
+    const int s = (c.n_pad + chunk - 1) / chunk;
+    if (s > max_splits) max_splits = s;
+    const size_t need = (size_t)s * K * c.n;
+    if (need > c.part_cap) {
+      hipFree(c.part_d); hipFree(c.part_i);
+      c.part_d = nullptr; c.part_i = nullptr;
+      HIP_TRY(h, hipMalloc(&c.part_d, sizeof(float) * need));
+      HIP_TRY(h, hipMalloc(&c.part_i, sizeof(int) * need));
+      c.part_cap = need;
+    }
+    if (c.knn_k != k || !c.knn) {
+      hipFree(c.knn);
+      c.knn = nullptr;
+      HIP_TRY(h, hipMalloc(&c.knn, sizeof(int) * (size_t)c.cap * k));
+      c.knn_k = k;
+    }
+    KnnJob& j = jobs[q];
+    j.cloud = c.view();
+    j.part_d = c.part_d;
+    j.part_i = c.part_i;
+    j.knn_out = c.knn;
+    j.k = k;
+    j.regularization = h->params.regularization;
+    j.splits = s;
+    j.chunk_len = chunk;
+  }
+  if (njobs > lead->jobs_cap) {
+    hipFree(lead->d_jobs);
+    lead->d_jobs = nullptr;
+    HIP_TRY(lead, hipMalloc(&lead->d_jobs, sizeof(KnnJob) * njobs));
+    lead->jobs_cap = njobs;
+  }
+  HIP_TRY(lead, hipMemcpyAsync(lead->d_jobs, jobs.data(), sizeof(KnnJob) * njobs, hipMemcpyHostToDevice, lead->stream));
+  HIP_TRY(lead, hipStreamSynchronize(lead->stream));  // jobs vector is pageable host memory
+  {
+    StageTimer t(lead, 0);
+    dim3 g1((max_n + 255) / 256, max_splits, njobs), g2((max_n + 255) / 256, 1, njobs);
+    if (K == 20) {
+      knn_partial_kernel<20><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
+      cov_finalize_kernel<20><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
+    } else {
+      knn_partial_kernel<32><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
+      cov_finalize_kernel<32><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
+    }
+  }
+  HIP_TRY(lead, hipGetLastError());
+  for (auto& t : todo) t.second->cov_count = t.second->n;
+  return GORIO_OK;
+}
+
+int check_ready(gorio_apd* h) {
+  if (!h->src.present) return fail(h, GORIO_ERR_STATE, "no input source set (setInputSource)");
+  if (!h->tgt.present) return fail(h, GORIO_ERR_STATE, "no input target set (setInputTarget)");
+  const gorio_apd_params& p = h->params;
+  if (p.k_correspondences < 1 || p.k_correspondences > 32) return fail(h, GORIO_ERR_UNSUPPORTED, "k_correspondences must be in [1, 32]");
+  if (p.regularization < 0 || p.regularization > 4) return fail(h, GORIO_ERR_UNSUPPORTED, "unknown regularization method (the reference aborts here, APD:389-391)");
+  if (h->src.cov_count != h->src.n && h->src.n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "source cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
+  if (h->tgt.cov_count != h->tgt.n && h->tgt.n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "target cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
+  return GORIO_OK;
+}
+
+void fill_desc(gorio_apd* h, PairDesc& d, PairState* state, long total_src_waves) {
+  d.src = h->src.view();
+  d.tgt = h->tgt.view();
+  d.best_key = h->best_key;
+  d.corr = h->corr;
+  d.sqd = h->sqd;
+  d.omega6 = h->omega6;
+  d.partials = h->partials;
+  d.state = state;
+  d.nblk = (h->src.n + 255) / 256;
+  int splits = (int)((8192 + total_src_waves - 1) / total_src_waves);
+  if (splits < 1) splits = 1;
+  if (splits > 64) splits = 64;
+  int chunk = roundup((h->tgt.n_pad + splits - 1) / splits, kPad);
+  if (chunk < 512) chunk = 512;
+  d.nn_chunk = chunk;
+  d.nn_splits = (h->tgt.n_pad + chunk - 1) / chunk;
+  d.pad_ = 0;
+}
+
+void init_state(PairState& s, const double* T16) {
+  std::memset(&s, 0, sizeof(s));
+  for (int i = 0; i < 16; ++i) s.x0[i] = T16[i];
+  s.x0[12] = 0; s.x0[13] = 0; s.x0[14] = 0; s.x0[15] = 1;
+  for (int i = 0; i < 16; ++i) s.xi[i] = s.x0[i];
+  for (int i = 0; i < 12; ++i) s.Tf[i] = (float)s.x0[i];
+  s.lambda = -1.0;
+  for (int i = 0; i < 6; ++i) s.Hfin[i * 6 + i] = 1.0;  // final_hessian_.setIdentity(), LSQ:23
+}
+
+int ensure_batch(gorio_apd* lead, int count) {
+  if (count > lead->desc_cap) {
+    hipFree(lead->d_desc); hipFree(lead->d_states_batch);
+    lead->d_desc = nullptr; lead->d_states_batch = nullptr;
+    HIP_TRY(lead, hipMalloc(&lead->d_desc, sizeof(PairDesc) * count));
+    HIP_TRY(lead, hipMalloc(&lead->d_states_batch, sizeof(PairState) * count));
+    lead->desc_cap = count;
+  }
+  return GORIO_OK;
+}
+
+// Shared body of align / align_batch.
+int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, double* H_out, int* converged, int* nr_iterations, int* n_linearize) {
+  if (!hs || count <= 0 || !guesses || !T_out) return GORIO_ERR_INVALID;
+  gorio_apd* lead = hs[0];
+  if (!lead) return GORIO_ERR_INVALID;
+  HIP_TRY(lead, hipSetDevice(lead->device));
+  for (int q = 0; q < count; ++q) {
+    gorio_apd* h = hs[q];
+    if (!h) return fail(lead, GORIO_ERR_INVALID, "null handle in batch");
+    if (h->device != lead->device) return fail(lead, GORIO_ERR_INVALID, "all handles of a batch must live on one device");
+    int rc = check_ready(h);
+    if (rc) {
+      if (h != lead) lead->err = h->err;
+      return rc;
+    }
+    if (h != lead) HIP_TRY(lead, hipStreamSynchronize(h->stream));
+    rc = ensure_points(h, h->src.n);
+    if (rc) return rc;
+  }
+  // APD:149-154: covariances of whichever cloud is stale
+  std::vector<std::pair<gorio_apd*, DevCloud*>> todo;
+  for (int q = 0; q < count; ++q) {
+    gorio_apd* h = hs[q];
+    if (h->src.cov_count != h->src.n) todo.emplace_back(h, &h->src);
+    if (h->tgt.cov_count != h->tgt.n) todo.emplace_back(h, &h->tgt);
+  }
+  int rc = run_covariances(lead, todo);
+  if (rc) return rc;
+
+  rc = ensure_batch(lead, count);
+  if (rc) return rc;
+  long total_src_waves = 0;
+  int max_n = 0;
+  for (int q = 0; q < count; ++q) {
+    total_src_waves += (hs[q]->src.n + 63) / 64;
+    if (hs[q]->src.n > max_n) max_n = hs[q]->src.n;
+  }
+  std::vector<PairDesc> descs(count);
+  std::vector<PairState> states(count);
+  int max_splits = 1;
+  for (int q = 0; q < count; ++q) {
+    double T[16];
+    for (int i = 0; i < 16; ++i) T[i] = (double)guesses[(size_t)q * 16 + i];  // LSQ:56
+    init_state(states[q], T);
+    fill_desc(hs[q], descs[q], lead->d_states_batch + q, total_src_waves);
+    if (descs[q].nn_splits > max_splits) max_splits = descs[q].nn_splits;
+    HIP_TRY(lead, hipMemsetAsync(hs[q]->best_key, 0xff, sizeof(unsigned long long) * hs[q]->src.n, lead->stream));
+    hs[q]->corr_valid = true;
+  }
+  HIP_TRY(lead, hipMemcpyAsync(lead->d_desc, descs.data(), sizeof(PairDesc) * count, hipMemcpyHostToDevice, lead->stream));
+  HIP_TRY(lead, hipMemcpyAsync(lead->d_states_batch, states.data(), sizeof(PairState) * count, hipMemcpyHostToDevice, lead->stream));
+  HIP_TRY(lead, hipStreamSynchronize(lead->stream));
+
+  const ApdConsts cst = make_consts(lead->params);
+  const dim3 g_nn((max_n + 255) / 256, max_splits, count), g_lin((max_n + 255) / 256, 1, count), g_lm(count);
+  int launched = 0;
+  int chunk_iters = 4;
+  const int max_it = lead->params.max_iterations;
+  while (launched < max_it) {
+    const int todo_it = std::min(chunk_iters, max_it - launched);
+    for (int it = 0; it < todo_it; ++it) {
+      if (lead->profiling) {
+        { StageTimer t(lead, 1); nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(lead->d_desc); }
+        { StageTimer t(lead, 2); linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst); }
+        { StageTimer t(lead, 3); lm_solve_kernel<<<g_lm, 1024, 0, lead->stream>>>(lead->d_desc, cst, 0); }
+      } else {
+        nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(lead->d_desc);
+        linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst);
+        lm_solve_kernel<<<g_lm, 1024, 0, lead->stream>>>(lead->d_desc, cst, 0);
+      }
+    }
+    launched += todo_it;
+    HIP_TRY(lead, hipGetLastError());
+    HIP_TRY(lead, hipMemcpyAsync(states.data(), lead->d_states_batch, sizeof(PairState) * count, hipMemcpyDeviceToHost, lead->stream));
+    HIP_TRY(lead, hipStreamSynchronize(lead->stream));
+    bool all_done = true;
+    for (int q = 0; q < count; ++q) all_done = all_done && states[q].done;
+    if (all_done) break;
+  }
+  for (int q = 0; q < count; ++q) {
+    const PairState& s = states[q];
+    for (int i = 0; i < 12; ++i) T_out[(size_t)q * 16 + i] = (float)s.x0[i];  // LSQ:78
+    T_out[(size_t)q * 16 + 12] = 0.f; T_out[(size_t)q * 16 + 13] = 0.f; T_out[(size_t)q * 16 + 14] = 0.f; T_out[(size_t)q * 16 + 15] = 1.f;
+    if (H_out) std::memcpy(H_out + (size_t)q * 36, s.Hfin, sizeof(double) * 36);
+    if (converged) converged[q] = s.converged;
+    if (nr_iterations) nr_iterations[q] = s.nr_iterations;
+    if (n_linearize) n_linearize[q] = s.n_linearize;
+    if (s.lm_failed) hs[q]->err = "lm not converged!!";  // LSQ:72 prints this to stderr
+    // keep a copy of the final state in the handle's own slot so linearize/compute_error hooks can continue from it
+    HIP_TRY(lead, hipMemcpyAsync(hs[q]->d_state, lead->d_states_batch + q, sizeof(PairState), hipMemcpyDeviceToDevice, lead->stream));
+  }
+  HIP_TRY(lead, hipStreamSynchronize(lead->stream));
+  return GORIO_OK;
+}
+
+int single_desc(gorio_apd* h) {
+  int rc = ensure_batch(h, 1);
+  if (rc) return rc;
+  PairDesc d;
+  fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
+  HIP_TRY(h, hipMemcpyAsync(h->d_desc, &d, sizeof(PairDesc), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GORIO_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+
+extern "C" {
+
+void gorio_apd_default_params(gorio_apd_params* p) {
+  if (!p) return;
+  p->k_correspondences = 20;
+  p->regularization = GORIO_REG_PLANE;
+  p->dist_var = 0.86;
+  p->azimuth_var = 0.5;
+  p->elevation_var = 1.0;
+  p->corr_dist_threshold = (double)FLT_MAX;
+  p->max_iterations = 64;
+  p->rotation_epsilon = 2e-3;
+  p->transformation_epsilon = 5e-4;
+  p->optimizer = GORIO_OPT_LEVENBERG_MARQUARDT;
+  p->lm_max_iterations = 10;
+  p->lm_init_lambda_factor = 1e-9;
+  p->search = GORIO_SEARCH_BRUTE_FORCE;
+}
+
+int gorio_apd_create(gorio_apd_t** out, int device) {
+  if (!out) return GORIO_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GORIO_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return GORIO_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return GORIO_ERR_NO_DEVICE;
+  gorio_apd* h = new (std::nothrow) gorio_apd();
+  if (!h) return GORIO_ERR_ALLOC;
+  h->device = device;
+  gorio_apd_default_params(&h->params);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&h->d_state, sizeof(PairState)) != hipSuccess ||
+      hipMalloc(&h->d_fit, sizeof(double) * 4) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    delete h;
+    return GORIO_ERR_NO_DEVICE;
+  }
+  *out = h;
+  return GORIO_OK;
+}
+
+void gorio_apd_destroy(gorio_apd_t* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  free_cloud(h->src);
+  free_cloud(h->tgt);
+  hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
+  hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_fit);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* gorio_apd_last_error(const gorio_apd_t* h) { return h ? h->err.c_str() : "null handle"; }
+
+int gorio_apd_set_params(gorio_apd_t* h, const gorio_apd_params* p) {
+  if (!h || !p) return GORIO_ERR_INVALID;
+  if (p->k_correspondences < 1 || p->k_correspondences > 32) return fail(h, GORIO_ERR_UNSUPPORTED, "k_correspondences must be in [1, 32]");
+  if (p->regularization < 0 || p->regularization > 4) return fail(h, GORIO_ERR_UNSUPPORTED, "unknown regularization method");
+  if (p->optimizer != GORIO_OPT_GAUSS_NEWTON && p->optimizer != GORIO_OPT_LEVENBERG_MARQUARDT) return fail(h, GORIO_ERR_INVALID, "unknown optimizer");
+  h->params = *p;
+  return GORIO_OK;
+}
+
+int gorio_apd_get_params(const gorio_apd_t* h, gorio_apd_params* p) {
+  if (!h || !p) return GORIO_ERR_INVALID;
+  *p = h->params;
+  return GORIO_OK;
+}
+
+int gorio_apd_set_source(gorio_apd_t* h, const float* xyz, const float* label, int n, int stride) {
+  if (!h) return GORIO_ERR_INVALID;
+  h->corr_valid = false;
+  return upload_cloud(h, h->src, xyz, label, n, stride);
+}
+int gorio_apd_set_target(gorio_apd_t* h, const float* xyz, const float* label, int n, int stride) {
+  if (!h) return GORIO_ERR_INVALID;
+  h->corr_valid = false;
+  return upload_cloud(h, h->tgt, xyz, label, n, stride);
+}
+int gorio_apd_set_source_device(gorio_apd_t* h, const float* dx, const float* dy, const float* dz, const float* dl, int n) {
+  if (!h) return GORIO_ERR_INVALID;
+  h->corr_valid = false;
+  return upload_cloud_device(h, h->src, dx, dy, dz, dl, n);
+}
+int gorio_apd_set_target_device(gorio_apd_t* h, const float* dx, const float* dy, const float* dz, const float* dl, int n) {
+  if (!h) return GORIO_ERR_INVALID;
+  h->corr_valid = false;
+  return upload_cloud_device(h, h->tgt, dx, dy, dz, dl, n);
+}
+
+int gorio_apd_clear_source(gorio_apd_t* h) {
+  if (!h) return GORIO_ERR_INVALID;
+  h->src.present = false; h->src.n = 0; h->src.cov_count = 0; h->corr_valid = false;  // APD:101-105
+  return GORIO_OK;
+}
+int gorio_apd_clear_target(gorio_apd_t* h) {
+  if (!h) return GORIO_ERR_INVALID;
+  h->tgt.present = false; h->tgt.n = 0; h->tgt.cov_count = 0; h->corr_valid = false;  // APD:107-112
+  return GORIO_OK;
+}
+int gorio_apd_swap_source_and_target(gorio_apd_t* h) {
+  if (!h) return GORIO_ERR_INVALID;
+  std::swap(h->src, h->tgt);  // APD:90-92: clouds, trees and covariances change sides
+  h->corr_valid = false;      // APD:96-97
+  return GORIO_OK;
+}
+
+static int set_covs(gorio_apd* h, DevCloud& c, const double* cov, int n) {
+  if (!cov || n <= 0) return fail(h, GORIO_ERR_INVALID, "set_covariances: bad arguments");
+  if (!c.present || n != c.n) return fail(h, GORIO_ERR_STATE, "set_covariances: size does not match the cloud (the reference would recompute them, APD:149-154)");
+  HIP_TRY(h, hipSetDevice(h->device));
+  std::vector<double> c6((size_t)n * 6);
+  for (int i = 0; i < n; ++i) {
+    const double* m = cov + (size_t)i * 16;
+    double* o = c6.data() + (size_t)i * 6;
+    o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = m[5]; o[4] = m[6]; o[5] = m[10];
+  }
+  HIP_TRY(h, hipMemcpyAsync(c.cov6, c6.data(), sizeof(double) * 6 * n, hipMemcpyHostToDevice, h->stream));
+  geo_weight_kernel<<<(n + 255) / 256, 256, 0, h->stream>>>(c.cov6, c.geo_w, n);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  c.cov_count = n;
+  return GORIO_OK;
+}
+
+int gorio_apd_set_source_covariances(gorio_apd_t* h, const double* cov, int n) { return h ? set_covs(h, h->src, cov, n) : GORIO_ERR_INVALID; }
+int gorio_apd_set_target_covariances(gorio_apd_t* h, const double* cov, int n) { return h ? set_covs(h, h->tgt, cov, n) : GORIO_ERR_INVALID; }
+
+static int get_covs(gorio_apd* h, DevCloud& c, double* cov, int n) {
+  const int cnt = c.present ? c.cov_count : 0;
+  if (!cov || cnt == 0) return cnt;
+  const int m = n < cnt ? n : cnt;
+  if (hipSetDevice(h->device) != hipSuccess) return fail(h, GORIO_ERR_NO_DEVICE, "hipSetDevice failed");
+  std::vector<double> c6((size_t)m * 6);
+  if (hipMemcpyAsync(c6.data(), c.cov6, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+    return fail(h, GORIO_ERR_NO_DEVICE, "covariance download failed");
+  for (int i = 0; i < m; ++i) {
+    const double* s = c6.data() + (size_t)i * 6;
+    double* o = cov + (size_t)i * 16;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 0;
+    o[4] = s[1]; o[5] = s[3]; o[6] = s[4]; o[7] = 0;
+    o[8] = s[2]; o[9] = s[4]; o[10] = s[5]; o[11] = 0;
+    o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 0;
+  }
+  return cnt;
+}
+int gorio_apd_get_source_covariances(gorio_apd_t* h, double* cov, int n) { return h ? get_covs(h, h->src, cov, n) : GORIO_ERR_INVALID; }
+int gorio_apd_get_target_covariances(gorio_apd_t* h, double* cov, int n) { return h ? get_covs(h, h->tgt, cov, n) : GORIO_ERR_INVALID; }
+
+int gorio_apd_calculate_covariances(gorio_apd_t* h) {
+  if (!h) return GORIO_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const gorio_apd_params& p = h->params;
+  std::vector<std::pair<gorio_apd*, DevCloud*>> todo;
+  for (DevCloud* c : {&h->src, &h->tgt}) {
+    if (c->present && c->cov_count != c->n) {
+      if (c->n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
+      todo.emplace_back(h, c);
+    }
+  }
+  int rc = run_covariances(h, todo);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GORIO_OK;
+}
+
+int gorio_apd_get_knn_indices(gorio_apd_t* h, int which, int* idx, int n_times_k) {
+  if (!h || !idx) return GORIO_ERR_INVALID;
+  DevCloud& c = which == 0 ? h->src : h->tgt;
+  if (!c.present || !c.knn || c.cov_count != c.n) return fail(h, GORIO_ERR_STATE, "no k-NN result held for this cloud");
+  if (n_times_k != c.n * c.knn_k) return fail(h, GORIO_ERR_INVALID, "get_knn_indices: size mismatch");
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(idx, c.knn, sizeof(int) * (size_t)n_times_k, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GORIO_OK;
+}
+
+int gorio_apd_align(gorio_apd_t* h, const float guess[16], float T_out[16], double* H_out, int* converged, int* nr_iterations, int* n_linearize) {
+  if (!h) return GORIO_ERR_INVALID;
+  gorio_apd* hs[1] = {h};
+  return align_impl(hs, 1, guess, T_out, H_out, converged, nr_iterations, n_linearize);
+}
+
+int gorio_apd_align_batch(gorio_apd_t** handles, int count, const float* guesses, float* T_out, double* H_out, int* converged, int* nr_iterations, int* n_linearize) {
+  return align_impl(handles, count, guesses, T_out, H_out, converged, nr_iterations, n_linearize);
+}
+
+int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b, double* error) {
+  if (!h || !T) return GORIO_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = check_ready(h);
+  if (rc) return rc;
+  rc = ensure_points(h, h->src.n);
+  if (rc) return rc;
+  rc = gorio_apd_calculate_covariances(h);
+  if (rc) return rc;
+  rc = single_desc(h);
+  if (rc) return rc;
+  PairState s;
+  init_state(s, T);
+  HIP_TRY(h, hipMemcpyAsync(h->d_state, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->best_key, 0xff, sizeof(unsigned long long) * h->src.n, h->stream));
+  const ApdConsts cst = make_consts(h->params);
+  PairDesc d;
+  fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
+  const int nbx = (h->src.n + 255) / 256;
+  nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
+  linearize_kernel<<<dim3(nbx, 1, 1), 256, 0, h->stream>>>(h->d_desc, cst);
+  lm_solve_kernel<<<1, 1024, 0, h->stream>>>(h->d_desc, cst, 1);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(&s, h->d_state, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->corr_valid = true;
+  if (H && b) {
+    std::memcpy(H, s.H, sizeof(double) * 36);
+    std::memcpy(b, s.b, sizeof(double) * 6);
+  }
+  if (error) *error = s.y0;
+  return GORIO_OK;
+}
+
+int gorio_apd_compute_error(gorio_apd_t* h, const double T[16], double* error) {
+  if (!h || !T || !error) return GORIO_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (!h->corr_valid) return fail(h, GORIO_ERR_STATE, "compute_error needs the correspondences of a previous linearize / align");
+  int rc = single_desc(h);
+  if (rc) return rc;
+  double xi[16];
+  for (int i = 0; i < 16; ++i) xi[i] = T[i];
+  HIP_TRY(h, hipMemcpyAsync(reinterpret_cast<char*>(h->d_state) + offsetof(PairState, xi), xi, sizeof(xi), hipMemcpyHostToDevice, h->stream));
+  const ApdConsts cst = make_consts(h->params);
+  lm_solve_kernel<<<1, 1024, 0, h->stream>>>(h->d_desc, cst, 2);
+  HIP_TRY(h, hipGetLastError());
+  double yi = 0.0;
+  HIP_TRY(h, hipMemcpyAsync(&yi, reinterpret_cast<char*>(h->d_state) + offsetof(PairState, yi), sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  *error = yi;
+  return GORIO_OK;
+}
+
+int gorio_apd_get_correspondences(gorio_apd_t* h, int* corr, float* sq_dist, int n) {
+  if (!h) return GORIO_ERR_INVALID;
+  if (!h->corr_valid) return fail(h, GORIO_ERR_STATE, "no correspondences held");
+  if (n != h->src.n) return fail(h, GORIO_ERR_INVALID, "get_correspondences: size mismatch");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (corr) HIP_TRY(h, hipMemcpyAsync(corr, h->corr, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
+  if (sq_dist) HIP_TRY(h, hipMemcpyAsync(sq_dist, h->sqd, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GORIO_OK;
+}
+
+int gorio_apd_get_mahalanobis(gorio_apd_t* h, double* maha, int n) {
+  if (!h || !maha) return GORIO_ERR_INVALID;
+  if (!h->corr_valid) return fail(h, GORIO_ERR_STATE, "no Mahalanobis matrices held");
+  if (n != h->src.n) return fail(h, GORIO_ERR_INVALID, "get_mahalanobis: size mismatch");
+  HIP_TRY(h, hipSetDevice(h->device));
+  std::vector<double> o6((size_t)n * 6);
+  HIP_TRY(h, hipMemcpyAsync(o6.data(), h->omega6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) {
+    const double* s = o6.data() + (size_t)i * 6;
+    double* o = maha + (size_t)i * 16;
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = 0;
+    o[4] = s[1]; o[5] = s[3]; o[6] = s[4]; o[7] = 0;
+    o[8] = s[2]; o[9] = s[4]; o[10] = s[5]; o[11] = 0;
+    o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 0;
+  }
+  return GORIO_OK;
+}
+
+int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out, int n, int stride) {
+  if (!h || !T || !xyz_out) return GORIO_ERR_INVALID;
+  if (!h->src.present || n != h->src.n) return fail(h, GORIO_ERR_STATE, "transform_source: no matching source cloud");
+  if (stride < 12 || stride % 4) return fail(h, GORIO_ERR_INVALID, "transform_source: bad stride");
+  HIP_TRY(h, hipSetDevice(h->device));
+  float* d_out = nullptr;
+  HIP_TRY(h, hipMalloc(&d_out, sizeof(float) * 3 * (size_t)n));
+  TfArg tf;
+  for (int i = 0; i < 12; ++i) tf.m[i] = T[i];
+  transform_cloud_kernel<<<(n + 255) / 256, 256, 0, h->stream>>>(h->src.x, h->src.y, h->src.z, n, tf, d_out);
+  std::vector<float> tmp((size_t)n * 3);
+  hipError_t e = hipMemcpyAsync(tmp.data(), d_out, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(d_out);
+  if (e != hipSuccess) return fail(h, GORIO_ERR_NO_DEVICE, hipGetErrorString(e));
+  const int st = stride / 4;
+  for (int i = 0; i < n; ++i) {
+    float* o = xyz_out + (size_t)i * st;
+    o[0] = tmp[3 * (size_t)i]; o[1] = tmp[3 * (size_t)i + 1]; o[2] = tmp[3 * (size_t)i + 2];
+  }
+  return GORIO_OK;
+}
+
+int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double* score, double* inlier_fraction) {
+  if (!h || !T || !score) return GORIO_ERR_INVALID;
+  if (!h->src.present || !h->tgt.present) return fail(h, GORIO_ERR_STATE, "fitness_score: clouds not set");
+  HIP_TRY(h, hipSetDevice(h->device));
+  int rc = ensure_points(h, h->src.n);
+  if (rc) return rc;
+  rc = single_desc(h);
+  if (rc) return rc;
+  PairState s;
+  double Td[16];
+  for (int i = 0; i < 16; ++i) Td[i] = (double)T[i];
+  init_state(s, Td);
+  for (int i = 0; i < 12; ++i) s.Tf[i] = T[i];
+  HIP_TRY(h, hipMemcpyAsync(h->d_state, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->best_key, 0xff, sizeof(unsigned long long) * h->src.n, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_fit, 0, sizeof(double) * 4, h->stream));
+  PairDesc d;
+  fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
+  const int nbx = (h->src.n + 255) / 256;
+  nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
+  const double thr = h->params.corr_dist_threshold;
+  fitness_kernel<<<nbx, 256, 0, h->stream>>>(h->best_key, h->src.n, max_range, thr * thr, h->d_fit);
+  HIP_TRY(h, hipGetLastError());
+  double out[4];
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_fit, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->corr_valid = false;
+  *score = out[1] > 0 ? out[0] / out[1] : DBL_MAX;  // pcl: returns max double when no correspondence is in range
+  if (inlier_fraction) *inlier_fraction = out[2] / (double)h->src.n;
+  return GORIO_OK;
+}
+
+int gorio_apd_set_profiling(gorio_apd_t* h, int enable) {
+  if (!h) return GORIO_ERR_INVALID;
+  h->profiling = enable != 0;
+  for (int i = 0; i < 4; ++i) { h->stage_s[i] = 0; h->stage_n[i] = 0; }
+  return GORIO_OK;
+}
+
+int gorio_apd_get_stage_times(gorio_apd_t* h, double seconds[4], int counts[4]) {
+  if (!h) return GORIO_ERR_INVALID;
+  for (int i = 0; i < 4; ++i) {
+    if (seconds) seconds[i] = h->stage_s[i];
+    if (counts) counts[i] = h->stage_n[i];
+  }
+  return GORIO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// apd_device.h -- device-side data layout shared by apd_kernels.hip and apd_api.hip (not part of the public ABI).
+//
+// HBM layout of one cloud (FastAPDGICP::input_ / target_ + source_covs_ / target_covs_, APDH:109-110):
+//   x[n_pad], y[n_pad], z[n_pad], label[n_pad]  float SoA; n_pad = n rounded up to 16 (+16), padding coordinates = 1e30 so a
+//                                                padded candidate has distance +inf and can never win a search
+//   cov6[n][6]   double, upper triangle (c00 c01 c02 c11 c12 c22) of the 3x3 block of the 4x4 covariance (row/col 3 are 0)
+//   geo_w[n]     double, sigma3/sigma1 of the regularised covariance (APD:266-269; a pure function of cov6)
+// Per source point of a pair (FastAPDGICP::correspondences_, sq_distances_, mahalanobis_, APDH:111-114):
+//   best_key[n]  u64 (float bits of d) << 32 | target index, ~0 = armed / nothing found
+//   corr[n] int32, sqd[n] float, omega6[n][6] double (3x3 block of the Mahalanobis matrix; row/col 3 are 0, APD:218)
+#pragma once
+#include <stdint.h>
+
+namespace gorio {
+
+struct CloudView {
+  float* x;
+  float* y;
+  float* z;
+  float* label;
+  double* cov6;
+  double* geo_w;
+  int n;
+  int n_pad;
+};
+
+// device-resident optimiser state of one scan pair (the members of LsqRegistration, LSQH:75-84, plus loop bookkeeping)
+struct PairState {
+  double x0[16];    // current pose, row-major (x0_isom, LSQ:56)
+  double xi[16];    // trial pose of compute_error API calls
+  double H[36];     // last linearisation
+  double b[6];
+  double y0;        // error at x0 (LSQ:130)
+  double yi;        // error of the last compute_error API call
+  double lambda;    // lm_lambda_ (LSQ:58: reset to -1 per align)
+  double Hfin[36];  // final_hessian_
+  float Tf[12];     // float cast of x0 (APD:164) used by the next correspondence search
+  int iter;         // outer iterations executed so far
+  int done;         // loop finished (converged / LM failure / max_iterations)
+  int converged;    // converged_
+  int nr_iterations;  // nr_iterations_ (LSQ:68)
+  int lm_failed;    // "lm not converged!!" (LSQ:71-74)
+  int n_linearize;  // linearize() calls
+  int n_error;      // compute_error() trials
+  int pad_;
+};
+
+struct PairDesc {
+  CloudView src;
+  CloudView tgt;
+  unsigned long long* best_key;
+  int* corr;
+  float* sqd;
+  double* omega6;
+  double* partials;  // [nblk][28]
+  PairState* state;
+  int nblk;          // ceil(src.n / 256)
+  int nn_splits;     // target range split count for nn_search_kernel
+  int nn_chunk;      // candidates per split (multiple of 16)
+  int pad_;
+};
+
+struct KnnJob {
+  CloudView cloud;
+  float* part_d;  // [splits][K][n]
+  int* part_i;
+  int* knn_out;   // [n][k] or null
+  int k;
+  int regularization;
+  int splits;
+  int chunk_len;  // multiple of 16
+};
+
+struct ApdConsts {
+  double thr2;     // corr_dist_threshold_^2 (APD:183)
+  double dist_var; // distance_variance_
+  double sin_az;   // sin(azimuth_variance_ / 180 * pi)  (APD:196, evaluated on the host in double)
+  double sin_el;   // sin(elevation_variance_ / 180 * pi) (APD:197)
+  double rot_eps;
+  double trans_eps;
+  double lm_init_lambda_factor;
+  double inv_n_scale;  // 1.0 (numerator of cl_weight = 1.0 / correspondences_.size(), APD:273)
+  int optimizer;
+  int lm_max_iterations;
+  int max_iterations;
+  int pad_;
+};
+
+struct TfArg {
+  float m[12];
+};
+
+}  // namespace gorio

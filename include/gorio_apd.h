@@ -1,0 +1,146 @@
+/*
+ * gorio_apd.h -- C ABI of the MI355X-native APD-GICP scan-matching back end (libgorio_amd.so).
+ *
+ * The reference has no FFI for this path: the seam is C++ virtual dispatch through
+ * pcl::Registration<PointXYZINormal,PointXYZINormal>.  This header is the boundary a drop-in
+ * fast_gicp::FastAPDGICP uses underneath that class surface (go-rio_amd/host/fast_gicp/gicp/fast_apdgicp.hpp in this
+ * repository); every entry point cites the reference member it replaces.  Paths are relative to /root/reference:
+ *   APDH = fast_apdgicp/include/fast_gicp/gicp/fast_apdgicp.hpp
+ *   APD  = fast_apdgicp/include/fast_gicp/gicp/impl/fast_apdgicp_impl.hpp
+ *   LSQH = fast_apdgicp/include/fast_gicp/gicp/lsq_registration.hpp
+ *   LSQ  = fast_apdgicp/include/fast_gicp/gicp/impl/lsq_registration_impl.hpp
+ *   REG  = 4DRadarSLAM/src/radar_graph_slam/registrations.cpp
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all host pointers are caller-owned and only read / written during the call.
+ *  - 4x4 matrices are ROW-major (T[r*4+c]); pcl / Eigen matrices are column-major, the C++ shim transposes.
+ *  - covariances cross the ABI as n * 16 doubles (Eigen::Matrix4d per point, symmetric, row/col 3 zero), exactly the
+ *    element type of FastAPDGICP::source_covs_ / target_covs_ (APDH:109-110).
+ *  - return 0 on success, negative gorio_status otherwise; gorio_apd_last_error() gives the text.
+ *  - a handle is one FastAPDGICP object: not thread-safe, distinct handles are independent (SURVEY 8b "Threading").
+ *  - there is no CPU fallback: every compute entry point fails with GORIO_ERR_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef GORIO_APD_H
+#define GORIO_APD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GORIO_OK = 0,
+  GORIO_ERR_INVALID = -1,    /* bad argument (null pointer, n < k, ...) */
+  GORIO_ERR_NO_DEVICE = -2,  /* no usable HIP device / HIP runtime error */
+  GORIO_ERR_STATE = -3,      /* call order violated (align before setInputTarget, ...) */
+  GORIO_ERR_ALLOC = -4,
+  GORIO_ERR_UNSUPPORTED = -5 /* e.g. k_correspondences > 32, unknown regularisation (APD:389-391 aborts there) */
+} gorio_status;
+
+/* fast_gicp::RegularizationMethod, gicp_settings.hpp:6 (same order) */
+typedef enum { GORIO_REG_NONE = 0, GORIO_REG_MIN_EIG = 1, GORIO_REG_NORMALIZED_MIN_EIG = 2, GORIO_REG_PLANE = 3, GORIO_REG_FROBENIUS = 4 } gorio_regularization;
+/* fast_gicp::LSQ_OPTIMIZER_TYPE, lsq_registration.hpp:13 (same order) */
+typedef enum { GORIO_OPT_GAUSS_NEWTON = 0, GORIO_OPT_LEVENBERG_MARQUARDT = 1 } gorio_optimizer;
+/* correspondence search strategy; every mode returns the SAME indices (exact search, ties -> lowest index) */
+typedef enum { GORIO_SEARCH_BRUTE_FORCE = 0, GORIO_SEARCH_PRUNED = 1 } gorio_search;
+
+typedef struct {
+  int k_correspondences;         /* setCorrespondenceRandomness, APD:45; default 20 (APD:21); <= 32 */
+  int regularization;            /* setRegularizationMethod, APD:50; default PLANE (APD:25) */
+  double dist_var;               /* setDistVar APD:63; default 0.86 (APDH:118) */
+  double azimuth_var;            /* setAzimuthVar APD:55; default 0.5 deg (APDH:116) */
+  double elevation_var;          /* setElevationVar APD:59; default 1.0 deg (APDH:117) */
+  double corr_dist_threshold;    /* pcl setMaxCorrespondenceDistance (REG:44); default FLT_MAX (APD:23) */
+  int max_iterations;            /* pcl setMaximumIterations (REG:43); default 64 (LSQ:13) */
+  double rotation_epsilon;       /* setRotationEpsilon LSQ:30; default 2e-3 (LSQ:14) */
+  double transformation_epsilon; /* pcl setTransformationEpsilon (REG:42); default 5e-4 (LSQ:15) */
+  int optimizer;                 /* lsq_optimizer_type_, default LM (LSQ:17) */
+  int lm_max_iterations;         /* default 10 (LSQ:19) */
+  double lm_init_lambda_factor;  /* setInitialLambdaFactor LSQ:35; default 1e-9 (LSQ:20) */
+  int search;                    /* gorio_search; default brute force */
+} gorio_apd_params;
+
+typedef struct gorio_apd gorio_apd_t;
+
+/* FastAPDGICP::FastAPDGICP() APD:14-28 / ~FastAPDGICP APD:31.  device = HIP device ordinal. */
+int gorio_apd_create(gorio_apd_t** out, int device);
+void gorio_apd_destroy(gorio_apd_t* h);
+const char* gorio_apd_last_error(const gorio_apd_t* h);
+
+/* library defaults == constructor defaults of the reference (APD:14-28, LSQ:10-24, APDH:116-118) */
+void gorio_apd_default_params(gorio_apd_params* p);
+/* all setters of APD:34-65, LSQ:30-42 and the pcl::Registration setters used at REG:42-44, in one call */
+int gorio_apd_set_params(gorio_apd_t* h, const gorio_apd_params* p);
+int gorio_apd_get_params(const gorio_apd_t* h, gorio_apd_params* p);
+
+/*
+ * setInputSource APD:115-124 / setInputTarget APD:127-135.  xyz points at the first x; consecutive points are
+ * `point_stride_bytes` apart (48 for pcl::PointXYZINormal, 12 for packed xyz); label points at the first cluster label
+ * (PointXYZINormal::normal_x, written by preprocessing_nodelet_ntu.cpp:561-568) with the same stride, or NULL (all 0).
+ * Copies the cloud to the device as SoA and invalidates that cloud's covariances (APD:122, 133).  The pointer-equality
+ * early-out of APD:116-118 / 128-130 is the C++ shim's job (it owns the shared_ptrs).
+ */
+int gorio_apd_set_source(gorio_apd_t* h, const float* xyz, const float* label, int n, int point_stride_bytes);
+int gorio_apd_set_target(gorio_apd_t* h, const float* xyz, const float* label, int n, int point_stride_bytes);
+/* Same, from DEVICE-resident SoA buffers (x, y, z, label each n floats; label may be NULL): device-to-device copy. */
+int gorio_apd_set_source_device(gorio_apd_t* h, const float* d_x, const float* d_y, const float* d_z, const float* d_label, int n);
+int gorio_apd_set_target_device(gorio_apd_t* h, const float* d_x, const float* d_y, const float* d_z, const float* d_label, int n);
+
+/* clearSource APD:101-105, clearTarget APD:107-112, swapSourceAndTarget APD:89-98 */
+int gorio_apd_clear_source(gorio_apd_t* h);
+int gorio_apd_clear_target(gorio_apd_t* h);
+int gorio_apd_swap_source_and_target(gorio_apd_t* h);
+
+/* setSourceCovariances APD:138-140 / setTargetCovariances APD:143-145: n * 16 doubles */
+int gorio_apd_set_source_covariances(gorio_apd_t* h, const double* cov4x4, int n);
+int gorio_apd_set_target_covariances(gorio_apd_t* h, const double* cov4x4, int n);
+/* getSourceCovariances APDH:73-75 / getTargetCovariances APDH:77-79.  Returns the number of covariances currently held
+ * (0 when stale, as source_covs_.size() would); copies min(count, n) of them when cov4x4 != NULL. */
+int gorio_apd_get_source_covariances(gorio_apd_t* h, double* cov4x4, int n);
+int gorio_apd_get_target_covariances(gorio_apd_t* h, double* cov4x4, int n);
+/* calculate_covariances APD:351-411 for whichever cloud is stale (what computeTransformation does first, APD:149-154) */
+int gorio_apd_calculate_covariances(gorio_apd_t* h);
+/* parity hook: the k neighbour indices (sorted by distance, ties by index) used for cloud `which` (0 source, 1 target);
+ * idx holds n*k ints.  Only valid after the covariances were computed by this library. */
+int gorio_apd_get_knn_indices(gorio_apd_t* h, int which, int* idx, int n_times_k);
+
+/*
+ * computeTransformation APD:148-157 + LsqRegistration::computeTransformation LSQ:55-80 (what pcl::Registration::align
+ * dispatches to).  guess / T_out: row-major float 4x4 (final_transformation_, LSQ:78); H_out: 36 doubles
+ * (final_hessian_, LSQ:120/168; may be NULL); converged = hasConverged(); nr_iterations = nr_iterations_ (LSQ:68).
+ * n_linearize (may be NULL) = number of linearize() calls executed = the unit of the throughput metric.
+ */
+int gorio_apd_align(gorio_apd_t* h, const float guess[16], float T_out[16], double* H_out, int* converged, int* nr_iterations, int* n_linearize);
+
+/* same for `count` independent handles advanced in lock-step on one device (one launch set per iteration).
+ * guesses / T_out: count * 16 floats; H_out: count * 36 doubles or NULL; the int outputs: count entries or NULL. */
+int gorio_apd_align_batch(gorio_apd_t** handles, int count, const float* guesses, float* T_out, double* H_out, int* converged, int* nr_iterations, int* n_linearize);
+
+/* linearize APD:224-307 (== evaluateCost LSQ:50-52 with a double pose): updates correspondences + Mahalanobis matrices at
+ * T (row-major double 4x4) and returns H (36, may be NULL together with b), b (6) and the weighted error. */
+int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b, double* error);
+/* compute_error APD:310-346: error at T with the correspondences / Mahalanobis matrices of the last linearize */
+int gorio_apd_compute_error(gorio_apd_t* h, const double T[16], double* error);
+/* parity hooks: correspondences_ / sq_distances_ (APDH:113-114) and mahalanobis_ (APDH:111; n*16 doubles, row/col 3 zero;
+ * entries of rejected points are zero) of the last linearize */
+int gorio_apd_get_correspondences(gorio_apd_t* h, int* corr, float* sq_dist, int n);
+int gorio_apd_get_mahalanobis(gorio_apd_t* h, double* maha4x4, int n);
+
+/* pcl::transformPointCloud(*input_, output, final_transformation_) of LSQ:79 on the device-resident source:
+ * xyz_out strided like set_source's input (only x, y, z are written). */
+int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out, int n, int point_stride_bytes);
+
+/* pcl::Registration::getFitnessScore(max_range) as the callers use it (scan_matching_odometry_nodelet.cpp:675,
+ * loop_detector.cpp:411): mean squared NN distance (<= max_range) of the source moved by T; also the inlier fraction
+ * of publish_scan_matching_status (SMO:679-689) when inlier_fraction != NULL. */
+int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double* score, double* inlier_fraction);
+
+/* seconds spent inside device kernels of the last align / align_batch, by stage (HIP events on the launch stream):
+ * [0] covariance estimation, [1] correspondence search, [2] linearize, [3] LM/GN solve + error trials; plus launch counts
+ * in counts[0..3] (either may be NULL).  Filled only after gorio_apd_set_profiling(h, 1). */
+int gorio_apd_set_profiling(gorio_apd_t* h, int enable);
+int gorio_apd_get_stage_times(gorio_apd_t* h, double seconds[4], int counts[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GORIO_APD_H */

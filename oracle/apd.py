@@ -1,0 +1,198 @@
+"""ctypes binding of oracle/apd_oracle.c (CPU restatement of fast_apdgicp_impl.hpp / lsq_registration_impl.hpp).
+
+Test infrastructure only -- see oracle/__init__.py.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import BUILD_DIR, build
+
+REG_NONE, REG_MIN_EIG, REG_NORMALIZED_MIN_EIG, REG_PLANE, REG_FROBENIUS = range(5)
+OPT_GN, OPT_LM = 0, 1
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("k_correspondences", C.c_int),
+        ("regularization", C.c_int),
+        ("dist_var", C.c_double),
+        ("azimuth_var", C.c_double),
+        ("elevation_var", C.c_double),
+        ("corr_dist_threshold", C.c_double),
+        ("max_iterations", C.c_int),
+        ("rotation_epsilon", C.c_double),
+        ("transformation_epsilon", C.c_double),
+        ("optimizer", C.c_int),
+        ("lm_max_iterations", C.c_int),
+        ("lm_init_lambda_factor", C.c_double),
+        ("num_threads", C.c_int),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [("n_linearize", C.c_int), ("n_compute_error", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(BUILD_DIR, "libapd_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.apdo_linearize.restype = C.c_double
+        _lib.apdo_compute_error.restype = C.c_double
+    return _lib
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().apdo_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def launch_params(**kw) -> Params:
+    """Shipped values of launch/ntu_loop3.launch:85-96 on top of the library defaults."""
+    base = dict(corr_dist_threshold=2.0, transformation_epsilon=0.1, max_iterations=64, k_correspondences=20)
+    base.update(kw)
+    return default_params(**base)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def knn_self(xyz, k, num_threads=0):
+    xyz = _f32(xyz)
+    n = xyz.shape[0]
+    idx = np.empty((n, k), np.int32)
+    sqd = np.empty((n, k), np.float32)
+    rc = lib().apdo_knn_self(_p(xyz, C.c_float), n, k, _p(idx, C.c_int), _p(sqd, C.c_float), num_threads)
+    if rc != 0:
+        raise ValueError(f"apdo_knn_self rc={rc} (needs n >= k)")
+    return idx, sqd
+
+
+def covariances_from_knn(xyz, knn_idx, regularization=REG_PLANE, num_threads=0):
+    xyz = _f32(xyz)
+    knn_idx = np.ascontiguousarray(knn_idx, np.int32)
+    n, k = knn_idx.shape
+    cov = np.empty((n, 4, 4), np.float64)
+    rc = lib().apdo_covariances_from_knn(_p(xyz, C.c_float), n, _p(knn_idx, C.c_int), k, regularization, _p(cov, C.c_double), num_threads)
+    if rc != 0:
+        raise ValueError(f"apdo_covariances_from_knn rc={rc}")
+    return cov
+
+
+def calculate_covariances(xyz, params: Params):
+    xyz = _f32(xyz)
+    n = xyz.shape[0]
+    cov = np.empty((n, 4, 4), np.float64)
+    rc = lib().apdo_calculate_covariances(_p(xyz, C.c_float), n, C.byref(params), _p(cov, C.c_double))
+    if rc != 0:
+        raise ValueError(f"apdo_calculate_covariances rc={rc}")
+    return cov
+
+
+def geo_weights(cov):
+    cov = _f64(cov)
+    n = cov.shape[0]
+    w = np.empty(n, np.float64)
+    lib().apdo_geo_weights(_p(cov, C.c_double), n, _p(w, C.c_double))
+    return w
+
+
+def update_correspondences(T, src_xyz, tgt_xyz, src_cov, tgt_cov, params):
+    T = _f64(T)
+    src_xyz, tgt_xyz = _f32(src_xyz), _f32(tgt_xyz)
+    src_cov, tgt_cov = _f64(src_cov), _f64(tgt_cov)
+    n, m = src_xyz.shape[0], tgt_xyz.shape[0]
+    corr = np.empty(n, np.int32)
+    sqd = np.empty(n, np.float32)
+    maha = np.zeros((n, 4, 4), np.float64)
+    lib().apdo_update_correspondences(
+        _p(T, C.c_double), _p(src_xyz, C.c_float), n, _p(tgt_xyz, C.c_float), m, _p(src_cov, C.c_double), _p(tgt_cov, C.c_double),
+        C.byref(params), _p(corr, C.c_int), _p(sqd, C.c_float), _p(maha, C.c_double))
+    return corr, sqd, maha
+
+
+def linearize(T, src_xyz, src_label, tgt_xyz, tgt_label, src_cov, tgt_cov, params, geo_w=None):
+    """Returns (error, H 6x6, b 6, corr, sqd, maha)."""
+    T = _f64(T)
+    src_xyz, tgt_xyz = _f32(src_xyz), _f32(tgt_xyz)
+    src_label, tgt_label = _f32(src_label), _f32(tgt_label)
+    src_cov, tgt_cov = _f64(src_cov), _f64(tgt_cov)
+    n, m = src_xyz.shape[0], tgt_xyz.shape[0]
+    if geo_w is None:
+        geo_w = geo_weights(src_cov)
+    geo_w = _f64(geo_w)
+    corr = np.empty(n, np.int32)
+    sqd = np.empty(n, np.float32)
+    maha = np.zeros((n, 4, 4), np.float64)
+    H = np.zeros((6, 6), np.float64)
+    b = np.zeros(6, np.float64)
+    err = lib().apdo_linearize(
+        _p(T, C.c_double), _p(src_xyz, C.c_float), _p(src_label, C.c_float), n, _p(tgt_xyz, C.c_float), _p(tgt_label, C.c_float), m,
+        _p(src_cov, C.c_double), _p(tgt_cov, C.c_double), _p(geo_w, C.c_double), C.byref(params),
+        _p(corr, C.c_int), _p(sqd, C.c_float), _p(maha, C.c_double), _p(H, C.c_double), _p(b, C.c_double))
+    return err, H, b, corr, sqd, maha
+
+
+def compute_error(T, src_xyz, src_label, tgt_xyz, tgt_label, geo_w, params, corr, maha):
+    T = _f64(T)
+    src_xyz, tgt_xyz = _f32(src_xyz), _f32(tgt_xyz)
+    src_label, tgt_label = _f32(src_label), _f32(tgt_label)
+    geo_w, maha = _f64(geo_w), _f64(maha)
+    corr = np.ascontiguousarray(corr, np.int32)
+    n = src_xyz.shape[0]
+    return lib().apdo_compute_error(
+        _p(T, C.c_double), _p(src_xyz, C.c_float), _p(src_label, C.c_float), n, _p(tgt_xyz, C.c_float), _p(tgt_label, C.c_float),
+        _p(geo_w, C.c_double), C.byref(params), _p(corr, C.c_int), _p(maha, C.c_double))
+
+
+def align(guess, src_xyz, src_label, tgt_xyz, tgt_label, src_cov, tgt_cov, params, want_trace=False):
+    """Full LsqRegistration::computeTransformation.
+
+    Returns dict(T, H, converged, nr_iterations, n_linearize, n_compute_error[, trace, trace_corr]).
+    """
+    guess = _f32(guess)
+    src_xyz, tgt_xyz = _f32(src_xyz), _f32(tgt_xyz)
+    src_label, tgt_label = _f32(src_label), _f32(tgt_label)
+    src_cov, tgt_cov = _f64(src_cov), _f64(tgt_cov)
+    n, m = src_xyz.shape[0], tgt_xyz.shape[0]
+    T = np.zeros((4, 4), np.float32)
+    H = np.zeros((6, 6), np.float64)
+    conv, nit = C.c_int(0), C.c_int(0)
+    cnt = Counters()
+    trace = trace_corr = None
+    tp = cp = None
+    if want_trace:
+        trace = np.full((params.max_iterations, 4, 4), np.nan)
+        trace_corr = np.full((params.max_iterations, n), -2, np.int32)
+        tp, cp = _p(trace, C.c_double), _p(trace_corr, C.c_int)
+    rc = lib().apdo_align(
+        _p(guess, C.c_float), _p(src_xyz, C.c_float), _p(src_label, C.c_float), n, _p(tgt_xyz, C.c_float), _p(tgt_label, C.c_float), m,
+        _p(src_cov, C.c_double), _p(tgt_cov, C.c_double), C.byref(params), _p(T, C.c_float), _p(H, C.c_double),
+        C.byref(conv), C.byref(nit), C.byref(cnt), tp, cp)
+    if rc != 0:
+        raise RuntimeError(f"apdo_align rc={rc}")
+    out = dict(T=T, H=H, converged=bool(conv.value), nr_iterations=nit.value, n_linearize=cnt.n_linearize, n_compute_error=cnt.n_compute_error)
+    if want_trace:
+        out["trace"] = trace[: cnt.n_linearize]
+        out["trace_corr"] = trace_corr[: cnt.n_linearize]
+    return out

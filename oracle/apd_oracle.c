@@ -1,0 +1,809 @@
+/*
+ * apd_oracle.c -- CPU restatement of Go-RIO's APD-GICP scan matching (TEST INFRASTRUCTURE ONLY).
+ *
+ * This file is the parity oracle for the HIP path.  It is NOT part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product library
+ * (go-rio_amd/csrc) never links, includes or calls anything in oracle/.
+ *
+ * It restates, in plain C (no Eigen / PCL / FLANN, which are absent from the build image), the algorithm in
+ *   APD  = /root/reference/fast_apdgicp/include/fast_gicp/gicp/impl/fast_apdgicp_impl.hpp
+ *   LSQ  = /root/reference/fast_apdgicp/include/fast_gicp/gicp/impl/lsq_registration_impl.hpp
+ *   SO3  = /root/reference/fast_apdgicp/include/fast_gicp/so3/so3.hpp
+ * Each function cites the lines it follows.
+ *
+ * PARITY PINNING: the reference ships no test, golden vector or fixture that instantiates FastAPDGICP
+ *  and it cannot be compiled here (Eigen, PCL, FLANN missing).  The oracle is
+ * therefore pinned by (i) an independent NumPy/SciPy restatement of the same lines (oracle/apd_numpy.py,
+ * different code, same maths), (ii) known-transform recovery in the acceptance shape of the reference's
+ * gicp_test.cpp (0.05 m / 1 deg, forward / backward / swap), and (iii) analytic identities (identical clouds at
+ * identity => b = 0, correspondences = identity permutation).  Third-party arithmetic (PCL 1.10 kd-tree,
+ * Eigen 3.3.7 JacobiSVD / inverse / LDLT) is restated from its published algorithm: "parity unpinned" for
+ * those pieces, as recorded in DESIGN.md.
+ *
+ * Third-party behaviour restated here:
+ *  - pcl::search::KdTree::nearestKSearch == exact k-NN under FLANN L2_Simple<float>:
+ *        d = ((dx*dx) + dy*dy) + dz*dz   in float, no FMA (reference builds with -msse4.2 only).
+ *    Ties are resolved to the LOWEST index (FLANN's order is tree-dependent; we define it).
+ *  - Eigen::Isometry3f * Vector4f == coefficient product accumulated k = 0..3:
+ *        q_r = ((m_r0*x + m_r1*y) + m_r2*z) + m_r3*1   in float, no FMA.
+ *  - Eigen::JacobiSVD<Matrix3d> of a symmetric PSD matrix == symmetric eigen-decomposition with U == V,
+ *    singular values sorted descending (cyclic Jacobi here).
+ *  - Eigen::Matrix4d::inverse == adjugate / determinant (cofactor expansion).
+ *  - Eigen::LDLT<6x6> == LDL^T with symmetric diagonal pivoting.
+ *  - atan2(float,float) / sqrt(float) under `using namespace std` (APD:7, 198-199) are the float overloads.
+ *    They are restated as the correctly rounded float results (float)atan2((double)y,(double)x) and
+ *    (float)sqrt((double)x): glibc's own atan2f is within 1 ulp of that but is not the same function on every
+ *    libm, and the GPU has no glibc; the correctly rounded value is the one definition both sides can meet.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -fopenmp -msse4.2 -ffp-contract=off, the reference's flags
+ * fast_apdgicp/CMakeLists.txt:11-16 plus contraction explicitly off).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* enum order of fast_gicp::RegularizationMethod, gicp_settings.hpp:6 */
+enum { APDO_REG_NONE = 0, APDO_REG_MIN_EIG = 1, APDO_REG_NORMALIZED_MIN_EIG = 2, APDO_REG_PLANE = 3, APDO_REG_FROBENIUS = 4 };
+/* enum order of fast_gicp::LSQ_OPTIMIZER_TYPE, lsq_registration.hpp:13 */
+enum { APDO_OPT_GN = 0, APDO_OPT_LM = 1 };
+
+typedef struct {
+  int k_correspondences;          /* APD:21  (20) */
+  int regularization;             /* APD:25  (PLANE) */
+  double dist_var;                /* APDH:118 (0.86) */
+  double azimuth_var;             /* APDH:116 (0.5) */
+  double elevation_var;           /* APDH:117 (1.0) */
+  double corr_dist_threshold;     /* APD:23 float max; launch 2.0 */
+  int max_iterations;             /* LSQ:13 (64) */
+  double rotation_epsilon;        /* LSQ:14 (2e-3) */
+  double transformation_epsilon;  /* LSQ:15 (5e-4); launch 0.1 */
+  int optimizer;                  /* LSQ:17 (LM) */
+  int lm_max_iterations;          /* LSQ:19 (10) */
+  double lm_init_lambda_factor;   /* LSQ:20 (1e-9) */
+  int num_threads;                /* APD:34-42; 0 => omp max */
+} apdo_params;
+
+void apdo_default_params(apdo_params* p) {
+  p->k_correspondences = 20;
+  p->regularization = APDO_REG_PLANE;
+  p->dist_var = 0.86;
+  p->azimuth_var = 0.5;
+  p->elevation_var = 1.0;
+  p->corr_dist_threshold = (double)FLT_MAX;
+  p->max_iterations = 64;
+  p->rotation_epsilon = 2e-3;
+  p->transformation_epsilon = 5e-4;
+  p->optimizer = APDO_OPT_LM;
+  p->lm_max_iterations = 10;
+  p->lm_init_lambda_factor = 1e-9;
+  p->num_threads = 0;
+}
+
+static int nthreads(const apdo_params* p) {
+#ifdef _OPENMP
+  return p->num_threads > 0 ? p->num_threads : omp_get_max_threads();
+#else
+  (void)p;
+  return 1;
+#endif
+}
+
+/* ---------------------------------------------------------------- small dense helpers (row-major) */
+
+static void mat3_mul(const double* A, const double* B, double* C) {
+  double t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += A[i * 3 + k] * B[k * 3 + j];
+      t[i * 3 + j] = s;
+    }
+  memcpy(C, t, sizeof(t));
+}
+
+static void mat4_mul(const double* A, const double* B, double* C) {
+  double t[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      double s = 0.0;
+      for (int k = 0; k < 4; k++) s += A[i * 4 + k] * B[k * 4 + j];
+      t[i * 4 + j] = s;
+    }
+  memcpy(C, t, sizeof(t));
+}
+
+static void mat4_transpose(const double* A, double* At) {
+  double t[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) t[j * 4 + i] = A[i * 4 + j];
+  memcpy(At, t, sizeof(t));
+}
+
+/* Matrix4d::inverse (APD:217): adjugate / determinant by cofactor expansion. Returns 0 when singular. */
+static int mat4_inverse(const double* m, double* inv_out) {
+  double inv[16];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  if (det == 0.0) return 0;
+  double r = 1.0 / det;
+  for (int i = 0; i < 16; i++) inv_out[i] = inv[i] * r;
+  return 1;
+}
+
+static void mat3_inverse(const double* m, double* out) {
+  double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  double r = 1.0 / det;
+  double t[9];
+  t[0] = c00 * r;
+  t[1] = (m[2] * m[7] - m[1] * m[8]) * r;
+  t[2] = (m[1] * m[5] - m[2] * m[4]) * r;
+  t[3] = c01 * r;
+  t[4] = (m[0] * m[8] - m[2] * m[6]) * r;
+  t[5] = (m[2] * m[3] - m[0] * m[5]) * r;
+  t[6] = c02 * r;
+  t[7] = (m[1] * m[6] - m[0] * m[7]) * r;
+  t[8] = (m[0] * m[4] - m[1] * m[3]) * r;
+  memcpy(out, t, sizeof(t));
+}
+
+/*
+ * Symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations; eigenvalues returned sorted DESCENDING with
+ * matching eigenvector columns in V (row-major 3x3, column j = j-th eigenvector).  Stands in for
+ * Eigen::JacobiSVD<Matrix3d>(sym PSD, FullU|FullV) at APD:266 and APD:385: for a symmetric PSD matrix the SVD has
+ * U == V == eigenvectors and singular values == eigenvalues (sorted descending by Eigen).
+ */
+static void sym3_eigen(const double* A_in, double* evals, double* V) {
+  double A[9];
+  memcpy(A, A_in, sizeof(A));
+  for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-32 * diag || off == 0.0) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        double app = A[p * 3 + p], aqq = A[q * 3 + q];
+        double theta = (aqq - app) / (2.0 * apq);
+        double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        /* A <- J^T A J with J = rotation in the (p,q) plane */
+        for (int k = 0; k < 3; k++) {
+          double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq;
+          A[k * 3 + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 3; k++) {
+          double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk;
+          A[q * 3 + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 3; k++) {
+          double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+          V[k * 3 + p] = c * vkp - s * vkq;
+          V[k * 3 + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  double w[3] = {A[0], A[4], A[8]};
+  int order[3] = {0, 1, 2};
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2 - i; j++)
+      if (w[order[j]] < w[order[j + 1]]) {
+        int t = order[j];
+        order[j] = order[j + 1];
+        order[j + 1] = t;
+      }
+  double Vs[9];
+  for (int j = 0; j < 3; j++) {
+    evals[j] = w[order[j]];
+    for (int k = 0; k < 3; k++) Vs[k * 3 + j] = V[k * 3 + order[j]];
+  }
+  memcpy(V, Vs, sizeof(Vs));
+}
+
+/* geo_weight of APD:266-269 / APD:330-333: sigma_3 / sigma_1 of the (regularised) source covariance. */
+static double geo_weight_of(const double* cov4) {
+  double C[9] = {cov4[0], cov4[1], cov4[2], cov4[4], cov4[5], cov4[6], cov4[8], cov4[9], cov4[10]};
+  double w[3], V[9];
+  sym3_eigen(C, w, V);
+  double s0 = fabs(w[0]), s1 = fabs(w[1]), s2 = fabs(w[2]);
+  double smax = fmax(s0, fmax(s1, s2)), smin = fmin(s0, fmin(s1, s2));
+  return smin / smax;
+}
+
+/* ---------------------------------------------------------------- exact float metric (FLANN L2_Simple) */
+
+static inline float sqdist3f(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+/*
+ * Exact brute-force k-NN of every point in its own cloud (APD:364: kdtree.nearestKSearch(cloud->at(i), k, ...)),
+ * sorted ascending by (distance, index); includes the point itself.  idx_out: n*k int32, sqd_out: n*k float
+ * (either may be NULL).  Requires n >= k (reference quirk APD:366-369: fewer points leave columns uninitialised).
+ */
+int apdo_knn_self(const float* xyz, int n, int k, int* idx_out, float* sqd_out, int num_threads) {
+  if (n < k || k <= 0 || k > 64) return -1;
+#ifdef _OPENMP
+  int nt = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+  int nt = 1;
+#endif
+  (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    float bd[64];
+    int bi[64];
+    int cnt = 0;
+    const float qx = xyz[3 * i], qy = xyz[3 * i + 1], qz = xyz[3 * i + 2];
+    for (int j = 0; j < n; j++) {
+      float d = sqdist3f(qx, qy, qz, xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]);
+      if (cnt == k && !(d < bd[k - 1])) continue; /* j ascending: an equal distance never displaces a lower index */
+      int pos = cnt < k ? cnt : k - 1;
+      while (pos > 0 && d < bd[pos - 1]) {
+        bd[pos] = bd[pos - 1];
+        bi[pos] = bi[pos - 1];
+        pos--;
+      }
+      bd[pos] = d;
+      bi[pos] = j;
+      if (cnt < k) cnt++;
+    }
+    for (int j = 0; j < k; j++) {
+      if (idx_out) idx_out[(size_t)i * k + j] = bi[j];
+      if (sqd_out) sqd_out[(size_t)i * k + j] = bd[j];
+    }
+  }
+  return 0;
+}
+
+/*
+ * calculate_covariances, APD:351-411.  cov_out: n * 16 doubles, each a row-major 4x4 (Matrix4d is symmetric here so
+ * the storage order does not matter).  knn_idx: n*k neighbour indices (from apdo_knn_self).
+ */
+int apdo_covariances_from_knn(const float* xyz, int n, const int* knn_idx, int k, int regularization, double* cov_out, int num_threads) {
+#ifdef _OPENMP
+  int nt = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+  int nt = 1;
+#endif
+  (void)nt;
+  int bad = 0;
+#pragma omp parallel for num_threads(nt) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    /* APD:366-372: neighbours as doubles, subtract the row mean, cov = X X^T / k (4th row/col are exactly 0) */
+    double mean[3] = {0, 0, 0};
+    for (int j = 0; j < k; j++) {
+      const float* p = xyz + 3 * (size_t)knn_idx[(size_t)i * k + j];
+      mean[0] += (double)p[0];
+      mean[1] += (double)p[1];
+      mean[2] += (double)p[2];
+    }
+    mean[0] /= (double)k;
+    mean[1] /= (double)k;
+    mean[2] /= (double)k;
+    double C[9] = {0};
+    for (int j = 0; j < k; j++) {
+      const float* p = xyz + 3 * (size_t)knn_idx[(size_t)i * k + j];
+      double d[3] = {(double)p[0] - mean[0], (double)p[1] - mean[1], (double)p[2] - mean[2]};
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) C[a * 3 + b] += d[a] * d[b];
+    }
+    for (int a = 0; a < 9; a++) C[a] /= (double)k;
+
+    double R[9];
+    if (regularization == APDO_REG_NONE) { /* APD:374-376 */
+      memcpy(R, C, sizeof(R));
+    } else if (regularization == APDO_REG_FROBENIUS) { /* APD:377-383 */
+      double Cl[9], Ci[9], N[9];
+      memcpy(Cl, C, sizeof(Cl));
+      Cl[0] += 1e-3;
+      Cl[4] += 1e-3;
+      Cl[8] += 1e-3;
+      mat3_inverse(Cl, Ci);
+      double fro = 0.0;
+      for (int a = 0; a < 9; a++) fro += Ci[a] * Ci[a];
+      fro = sqrt(fro);
+      for (int a = 0; a < 9; a++) N[a] = Ci[a] / fro;
+      mat3_inverse(N, R);
+    } else { /* APD:384-406 */
+      double w[3], V[9], vals[3];
+      sym3_eigen(C, w, V);
+      double s[3] = {fabs(w[0]), fabs(w[1]), fabs(w[2])};
+      if (regularization == APDO_REG_PLANE) {
+        vals[0] = 1.0;
+        vals[1] = 1.0;
+        vals[2] = 1e-3;
+      } else if (regularization == APDO_REG_MIN_EIG) {
+        for (int a = 0; a < 3; a++) vals[a] = fmax(s[a], 1e-3);
+      } else if (regularization == APDO_REG_NORMALIZED_MIN_EIG) {
+        double smax = fmax(s[0], fmax(s[1], s[2]));
+        for (int a = 0; a < 3; a++) vals[a] = fmax(s[a] / smax, 1e-3);
+      } else {
+#pragma omp atomic write
+        bad = 1; /* APD:389-391 abort() */
+        continue;
+      }
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) R[a * 3 + b] = V[a * 3 + 0] * vals[0] * V[b * 3 + 0] + V[a * 3 + 1] * vals[1] * V[b * 3 + 1] + V[a * 3 + 2] * vals[2] * V[b * 3 + 2];
+    }
+    double* o = cov_out + (size_t)i * 16;
+    memset(o, 0, 16 * sizeof(double));
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) o[a * 4 + b] = R[a * 3 + b];
+  }
+  return bad ? -2 : 0;
+}
+
+int apdo_calculate_covariances(const float* xyz, int n, const apdo_params* p, double* cov_out) {
+  int k = p->k_correspondences;
+  int* idx = (int*)malloc((size_t)n * k * sizeof(int));
+  if (!idx) return -3;
+  int rc = apdo_knn_self(xyz, n, k, idx, NULL, p->num_threads);
+  if (rc == 0) rc = apdo_covariances_from_knn(xyz, n, idx, k, p->regularization, cov_out, p->num_threads);
+  free(idx);
+  return rc;
+}
+
+/* ---------------------------------------------------------------- correspondences + Mahalanobis (APD:160-220) */
+
+/* trans.cast<float>() then `trans_f * p` (APD:164, 176): Eigen coefficient product, float, no FMA. */
+static inline void transform_point_f(const float* Tf, float x, float y, float z, float* q) {
+  for (int r = 0; r < 3; r++) {
+    float a = Tf[r * 4 + 0] * x;
+    a = a + Tf[r * 4 + 1] * y;
+    a = a + Tf[r * 4 + 2] * z;
+    a = a + Tf[r * 4 + 3]; /* * 1.0f is exact */
+    q[r] = a;
+  }
+}
+
+/* sensor covariance cov_r at the transformed point, APD:194-210 */
+static void sensor_cov(const apdo_params* p, const float* q, double* cov_r) {
+  double px = (double)q[0], py = (double)q[1], pz = (double)q[2];
+  double dist = sqrt(px * px + py * py + pz * pz);                    /* APD:194 */
+  double s_x = dist * p->dist_var / 400;                              /* APD:195 */
+  double s_y = dist * sin(p->azimuth_var / 180 * M_PI);               /* APD:196 */
+  double s_z = dist * sin(p->elevation_var / 180 * M_PI);             /* APD:197 */
+  float rxy = (float)sqrt((double)(q[0] * q[0] + q[1] * q[1]));       /* sqrt(float): float overload, argument evaluated in float */
+  double elevation = (double)(float)atan2((double)rxy, (double)q[2]); /* APD:198 atan2(float,float) */
+  double azimuth = (double)(float)atan2((double)q[1], (double)q[0]);  /* APD:199 */
+  double ce = cos(elevation), se = sin(elevation), ca = cos(azimuth), sa = sin(azimuth);
+  /* R = yaw(Z, azimuth) * pitch(Y, elevation), APD:200-203 */
+  double Rz[9] = {ca, -sa, 0, sa, ca, 0, 0, 0, 1};
+  double Ry[9] = {ce, 0, se, 0, 1, 0, -se, 0, ce};
+  double R[9], A[9];
+  mat3_mul(Rz, Ry, R);
+  double S[9] = {s_x, 0, 0, 0, s_y, 0, 0, 0, s_z}; /* APD:204-205 */
+  mat3_mul(R, S, A);                               /* APD:207 */
+  for (int a = 0; a < 3; a++)                      /* APD:208 cov_r = A A^T */
+    for (int b = 0; b < 3; b++) cov_r[a * 3 + b] = A[a * 3 + 0] * A[b * 3 + 0] + A[a * 3 + 1] * A[b * 3 + 1] + A[a * 3 + 2] * A[b * 3 + 2];
+}
+
+/*
+ * update_correspondences, APD:160-220.  T: row-major 4x4 double (Isometry3d).  Brute-force exact 1-NN with ties to
+ * the lowest index.  Outputs: corr[n] (-1 when rejected), sqd[n], maha[n*16] (row-major 4x4; untouched for rejected).
+ */
+int apdo_update_correspondences(const double* T, const float* src_xyz, int n, const float* tgt_xyz, int m, const double* src_cov, const double* tgt_cov, const apdo_params* p, int* corr, float* sqd, double* maha) {
+  float Tf[16];
+  for (int i = 0; i < 16; i++) Tf[i] = (float)T[i]; /* APD:164 */
+  double Tt[16];
+  mat4_transpose(T, Tt);
+  int nt = nthreads(p);
+  (void)nt;
+  const double thr2 = p->corr_dist_threshold * p->corr_dist_threshold;
+#pragma omp parallel for num_threads(nt) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    float q[3];
+    transform_point_f(Tf, src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2], q); /* APD:176 */
+    float best = INFINITY;
+    int bj = -1;
+    for (int j = 0; j < m; j++) { /* APD:178 */
+      float d = sqdist3f(q[0], q[1], q[2], tgt_xyz[3 * j], tgt_xyz[3 * j + 1], tgt_xyz[3 * j + 2]);
+      if (d < best) {
+        best = d;
+        bj = j;
+      }
+    }
+    sqd[i] = best;                                  /* APD:180 */
+    corr[i] = ((double)best < thr2) ? bj : -1;      /* APD:183 */
+    if (corr[i] < 0) continue;                      /* APD:185-187 */
+    const double* cA = src_cov + (size_t)i * 16;
+    const double* cB = tgt_cov + (size_t)corr[i] * 16;
+    double cr[9];
+    sensor_cov(p, q, cr);
+    double A4[16], B4[16];
+    for (int a = 0; a < 16; a++) {
+      A4[a] = cA[a];
+      B4[a] = cB[a];
+    }
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) { /* cov + cov_dist, APD:209-214 */
+        A4[a * 4 + b] += cr[a * 3 + b];
+        B4[a * 4 + b] += cr[a * 3 + b];
+      }
+    double TA[16], TAT[16], RCR[16];
+    mat4_mul(T, A4, TA);
+    mat4_mul(TA, Tt, TAT);
+    for (int a = 0; a < 16; a++) RCR[a] = B4[a] + TAT[a]; /* APD:214 */
+    RCR[15] = 1.0;                                         /* APD:215 */
+    double* M = maha + (size_t)i * 16;
+    if (!mat4_inverse(RCR, M)) {
+      for (int a = 0; a < 16; a++) M[a] = NAN;
+    }
+    M[15] = 0.0; /* APD:218 */
+  }
+  return 0;
+}
+
+/* error term shared by linearize / compute_error: APD:255-276 and APD:320-341 */
+static inline double point_error(const double* T, const float* a, const float* b, const double* M, double weight, double* Ta_out, double* e_out) {
+  double A4[4] = {(double)a[0], (double)a[1], (double)a[2], 1.0};
+  double B4[4] = {(double)b[0], (double)b[1], (double)b[2], 1.0};
+  double Ta[4], e[4];
+  for (int r = 0; r < 4; r++) Ta[r] = T[r * 4 + 0] * A4[0] + T[r * 4 + 1] * A4[1] + T[r * 4 + 2] * A4[2] + T[r * 4 + 3] * A4[3];
+  for (int r = 0; r < 4; r++) e[r] = B4[r] - Ta[r];
+  double q = 0.0;
+  for (int r = 0; r < 4; r++) {
+    double s = 0.0;
+    for (int c = 0; c < 4; c++) s += M[r * 4 + c] * e[c];
+    q += e[r] * s;
+  }
+  if (Ta_out) memcpy(Ta_out, Ta, sizeof(Ta));
+  if (e_out) memcpy(e_out, e, sizeof(e));
+  return weight * q;
+}
+
+/*
+ * linearize, APD:224-307 (calls update_correspondences first, APD:226).  H: 36 doubles row-major, b: 6 doubles;
+ * either may be NULL (then only the error is returned, APD:278-280).  corr / sqd / maha are the object's state.
+ * geo_w[n] = per-source-point sigma3/sigma1 of the regularised covariance (recomputed by the reference in every call,
+ * APD:266-269; a pure function of src_cov, precomputed by apdo_geo_weights).
+ */
+double apdo_linearize(const double* T, const float* src_xyz, const float* src_label, int n, const float* tgt_xyz, const float* tgt_label, int m, const double* src_cov, const double* tgt_cov, const double* geo_w, const apdo_params* p, int* corr, float* sqd, double* maha, double* H, double* b) {
+  apdo_update_correspondences(T, src_xyz, n, tgt_xyz, m, src_cov, tgt_cov, p, corr, sqd, maha);
+  int nt = nthreads(p);
+  double* Hs = (double*)calloc((size_t)nt * 36, sizeof(double));
+  double* bs = (double*)calloc((size_t)nt * 6, sizeof(double));
+  double sum_errors = 0.0;
+  const double cl = 1.0 / (double)n; /* 1.0 / correspondences_.size(), APD:273 */
+#pragma omp parallel for num_threads(nt) reduction(+ : sum_errors) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    int j = corr[i];
+    if (j < 0) continue;
+    const double* M = maha + (size_t)i * 16;
+    double w = 1.0 + geo_w[i] + ((tgt_label[j] == src_label[i]) ? cl : 0.0); /* APD:266-276 */
+    double Ta[4], e[4];
+    sum_errors += point_error(T, src_xyz + 3 * (size_t)i, tgt_xyz + 3 * (size_t)j, M, w, Ta, e);
+    if (!H || !b) continue;
+    /* J = [skew(Ta) | -I ; 0], APD:284-287 */
+    double J[4][6] = {{0}};
+    J[0][1] = -Ta[2];
+    J[0][2] = Ta[1];
+    J[1][0] = Ta[2];
+    J[1][2] = -Ta[0];
+    J[2][0] = -Ta[1];
+    J[2][1] = Ta[0];
+    J[0][3] = -1.0;
+    J[1][4] = -1.0;
+    J[2][5] = -1.0;
+    double MJ[4][6], Me[4];
+    for (int r = 0; r < 4; r++) {
+      for (int c = 0; c < 6; c++) {
+        double s = 0.0;
+        for (int kk = 0; kk < 4; kk++) s += M[r * 4 + kk] * J[kk][c];
+        MJ[r][c] = s;
+      }
+      double s = 0.0;
+      for (int kk = 0; kk < 4; kk++) s += M[r * 4 + kk] * e[kk];
+      Me[r] = s;
+    }
+#ifdef _OPENMP
+    int tid = omp_get_thread_num();
+#else
+    int tid = 0;
+#endif
+    double* Ht = Hs + (size_t)tid * 36;
+    double* bt = bs + (size_t)tid * 6;
+    for (int r = 0; r < 6; r++) { /* APD:289-293 (H, b NOT weighted) */
+      for (int c = 0; c < 6; c++) {
+        double s = 0.0;
+        for (int kk = 0; kk < 4; kk++) s += J[kk][r] * MJ[kk][c];
+        Ht[r * 6 + c] += s;
+      }
+      double s = 0.0;
+      for (int kk = 0; kk < 4; kk++) s += J[kk][r] * Me[kk];
+      bt[r] += s;
+    }
+  }
+  if (H && b) { /* APD:297-304 */
+    memset(H, 0, 36 * sizeof(double));
+    memset(b, 0, 6 * sizeof(double));
+    for (int t = 0; t < nt; t++) {
+      for (int a = 0; a < 36; a++) H[a] += Hs[(size_t)t * 36 + a];
+      for (int a = 0; a < 6; a++) b[a] += bs[(size_t)t * 6 + a];
+    }
+  }
+  free(Hs);
+  free(bs);
+  return sum_errors;
+}
+
+/* compute_error, APD:310-346: stale correspondences and Mahalanobis matrices of the last linearize. */
+double apdo_compute_error(const double* T, const float* src_xyz, const float* src_label, int n, const float* tgt_xyz, const float* tgt_label, const double* geo_w, const apdo_params* p, const int* corr, const double* maha) {
+  int nt = nthreads(p);
+  (void)nt;
+  double sum_errors = 0.0;
+  const double cl = 1.0 / (double)n;
+#pragma omp parallel for num_threads(nt) reduction(+ : sum_errors) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    int j = corr[i];
+    if (j < 0) continue;
+    double w = 1.0 + geo_w[i] + ((tgt_label[j] == src_label[i]) ? cl : 0.0);
+    sum_errors += point_error(T, src_xyz + 3 * (size_t)i, tgt_xyz + 3 * (size_t)j, maha + (size_t)i * 16, w, NULL, NULL);
+  }
+  return sum_errors;
+}
+
+void apdo_geo_weights(const double* cov, int n, double* geo_w) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) geo_w[i] = geo_weight_of(cov + (size_t)i * 16);
+}
+
+/* ---------------------------------------------------------------- optimiser shell (LSQ) */
+
+/* Eigen::LDLT<6x6>(A).solve(rhs): LDL^T with symmetric diagonal pivoting (largest |diagonal|). */
+static void ldlt6_solve(const double* A_in, const double* rhs, double* x) {
+  const int N = 6;
+  double A[36];
+  memcpy(A, A_in, sizeof(A));
+  int perm[6];
+  for (int i = 0; i < N; i++) perm[i] = i;
+  for (int k = 0; k < N; k++) {
+    int piv = k;
+    double best = fabs(A[k * N + k]);
+    for (int i = k + 1; i < N; i++)
+      if (fabs(A[i * N + i]) > best) {
+        best = fabs(A[i * N + i]);
+        piv = i;
+      }
+    if (piv != k) {
+      for (int c = 0; c < N; c++) {
+        double t = A[k * N + c];
+        A[k * N + c] = A[piv * N + c];
+        A[piv * N + c] = t;
+      }
+      for (int r = 0; r < N; r++) {
+        double t = A[r * N + k];
+        A[r * N + k] = A[r * N + piv];
+        A[r * N + piv] = t;
+      }
+      int t = perm[k];
+      perm[k] = perm[piv];
+      perm[piv] = t;
+    }
+    double d = A[k * N + k];
+    if (d == 0.0) continue;
+    double col[6];
+    for (int i = k + 1; i < N; i++) col[i] = A[i * N + k];
+    for (int i = k + 1; i < N; i++) {
+      double l = col[i] / d;
+      for (int j = k + 1; j <= i; j++) A[i * N + j] -= l * col[j];
+      A[i * N + k] = l;
+    }
+    for (int i = k + 1; i < N; i++)
+      for (int j = i + 1; j < N; j++) A[i * N + j] = A[j * N + i];
+  }
+  double y[6];
+  for (int i = 0; i < N; i++) y[i] = rhs[perm[i]];
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < i; j++) y[i] -= A[i * N + j] * y[j];
+  for (int i = 0; i < N; i++) y[i] = (A[i * N + i] != 0.0) ? y[i] / A[i * N + i] : 0.0;
+  for (int i = N - 1; i >= 0; i--)
+    for (int j = i + 1; j < N; j++) y[i] -= A[j * N + i] * y[j];
+  for (int i = 0; i < N; i++) x[perm[i]] = y[i];
+}
+
+/* so3_exp (SO3:59-78) -> Quaterniond -> toRotationMatrix; delta (row-major 4x4) = [R | d[3:6]]  (LSQ:117-119, 140-142) */
+static void delta_from_d(const double* d, double* delta) {
+  double theta_sq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    double theta_quad = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * theta_quad;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * theta_quad;
+  } else {
+    double theta = sqrt(theta_sq);
+    double half = 0.5 * theta;
+    imag = sin(half) / theta;
+    real = cos(half);
+  }
+  double w = real, x = imag * d[0], y = imag * d[1], z = imag * d[2];
+  /* Eigen QuaternionBase::toRotationMatrix (no normalisation) */
+  double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  double R[9] = {1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.0 - (txx + tyy)};
+  memset(delta, 0, 16 * sizeof(double));
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) delta[r * 4 + c] = R[r * 3 + c];
+    delta[r * 4 + 3] = d[3 + r];
+  }
+  delta[15] = 1.0;
+}
+
+/* Isometry3d product delta * x0 (LSQ:119, 144) */
+static void isom_mul(const double* A, const double* B, double* C) {
+  double t[16];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) t[r * 4 + c] = A[r * 4 + 0] * B[0 * 4 + c] + A[r * 4 + 1] * B[1 * 4 + c] + A[r * 4 + 2] * B[2 * 4 + c];
+    t[r * 4 + 3] = A[r * 4 + 0] * B[3] + A[r * 4 + 1] * B[7] + A[r * 4 + 2] * B[11] + A[r * 4 + 3];
+  }
+  t[12] = t[13] = t[14] = 0.0;
+  t[15] = 1.0;
+  memcpy(C, t, sizeof(t));
+}
+
+/* is_converged, LSQ:83-92 */
+static int is_converged(const double* delta, const apdo_params* p) {
+  double rmax = 0.0, tmax = 0.0;
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) {
+      double v = fabs(delta[r * 4 + c] - (r == c ? 1.0 : 0.0)) * (1.0 / p->rotation_epsilon);
+      if (v > rmax) rmax = v;
+    }
+    double v = fabs(delta[r * 4 + 3]) * (1.0 / p->transformation_epsilon);
+    if (v > tmax) tmax = v;
+  }
+  return fmax(rmax, tmax) < 1.0;
+}
+
+/* Everything an align() needs; mirrors the members of FastAPDGICP (APDH:101-121) */
+typedef struct {
+  const float *src_xyz, *src_label, *tgt_xyz, *tgt_label;
+  int n, m;
+  const double *src_cov, *tgt_cov, *geo_w;
+  int* corr;
+  float* sqd;
+  double* maha;
+} apdo_state;
+
+typedef struct {
+  int n_linearize;      /* number of linearize() calls == GN/LM outer iterations executed */
+  int n_compute_error;  /* number of LM trial evaluations */
+} apdo_counters;
+
+/*
+ * LsqRegistration::computeTransformation, LSQ:55-80 with step_lm LSQ:127-173 and step_gn LSQ:107-123.
+ * guess: row-major 4x4 float (pcl Matrix4f).  Outputs: final_T (row-major float 4x4, LSQ:78), final_H (36),
+ * converged, nr_iterations (LSQ:68: index of the last iteration started).
+ * trace (optional, may be NULL): per outer iteration 16 doubles of x0 AFTER the step, up to max_iterations entries;
+ * trace_corr (optional): n ints per outer iteration = correspondences used by that iteration's linearize.
+ */
+int apdo_align(const float* guess, const float* src_xyz, const float* src_label, int n, const float* tgt_xyz, const float* tgt_label, int m, const double* src_cov, const double* tgt_cov, const apdo_params* p, float* final_T, double* final_H, int* converged_out, int* nr_iterations_out, apdo_counters* counters, double* trace, int* trace_corr) {
+  double x0[16];
+  for (int i = 0; i < 16; i++) x0[i] = (double)guess[i]; /* LSQ:56 */
+  x0[12] = x0[13] = x0[14] = 0.0;
+  x0[15] = 1.0;
+  double lm_lambda = -1.0; /* LSQ:58 */
+  int converged = 0;       /* LSQ:59 */
+  int nr_iterations = 0;
+  double Hfin[36];
+  for (int i = 0; i < 36; i++) Hfin[i] = (i % 7 == 0) ? 1.0 : 0.0; /* LSQ:23 */
+
+  int* corr = (int*)malloc((size_t)n * sizeof(int));
+  float* sqd = (float*)malloc((size_t)n * sizeof(float));
+  double* maha = (double*)malloc((size_t)n * 16 * sizeof(double));
+  double* geo_w = (double*)malloc((size_t)n * sizeof(double));
+  if (!corr || !sqd || !maha || !geo_w) return -3;
+  apdo_geo_weights(src_cov, n, geo_w);
+  apdo_counters cnt = {0, 0};
+
+  for (int it = 0; it < p->max_iterations && !converged; it++) { /* LSQ:67 */
+    nr_iterations = it;                                           /* LSQ:68 */
+    double H[36], b[6], delta[16], nb[6], d[6];
+    int ok = 0;
+    double y0 = apdo_linearize(x0, src_xyz, src_label, n, tgt_xyz, tgt_label, m, src_cov, tgt_cov, geo_w, p, corr, sqd, maha, H, b);
+    cnt.n_linearize++;
+    if (trace_corr) memcpy(trace_corr + (size_t)it * n, corr, (size_t)n * sizeof(int));
+    for (int i = 0; i < 6; i++) nb[i] = -b[i];
+    if (p->optimizer == APDO_OPT_GN) { /* LSQ:107-123 */
+      ldlt6_solve(H, nb, d);
+      delta_from_d(d, delta);
+      isom_mul(delta, x0, x0);
+      memcpy(Hfin, H, sizeof(H));
+      ok = 1;
+    } else { /* LSQ:127-173 */
+      if (lm_lambda < 0.0) {
+        double mx = 0.0;
+        for (int i = 0; i < 6; i++) mx = fmax(mx, fabs(H[i * 6 + i]));
+        lm_lambda = p->lm_init_lambda_factor * mx; /* LSQ:131-133 */
+      }
+      double nu = 2.0;
+      for (int j = 0; j < p->lm_max_iterations; j++) {
+        double Hl[36];
+        memcpy(Hl, H, sizeof(H));
+        for (int i = 0; i < 6; i++) Hl[i * 6 + i] += lm_lambda;
+        ldlt6_solve(Hl, nb, d); /* LSQ:137-138 */
+        delta_from_d(d, delta);
+        double xi[16];
+        isom_mul(delta, x0, xi); /* LSQ:144 */
+        double yi = apdo_compute_error(xi, src_xyz, src_label, n, tgt_xyz, tgt_label, geo_w, p, corr, maha);
+        cnt.n_compute_error++;
+        double den = 0.0;
+        for (int i = 0; i < 6; i++) den += d[i] * (lm_lambda * d[i] - b[i]);
+        double rho = (y0 - yi) / den; /* LSQ:146 */
+        if (rho < 0) {                /* LSQ:156-164 */
+          if (is_converged(delta, p)) {
+            ok = 1;
+            break;
+          }
+          lm_lambda = nu * lm_lambda;
+          nu = 2 * nu;
+          continue;
+        }
+        memcpy(x0, xi, sizeof(xi)); /* LSQ:166 */
+        double f = 1 - pow(2 * rho - 1, 3);
+        lm_lambda = lm_lambda * fmax(1.0 / 3.0, f); /* LSQ:167 */
+        memcpy(Hfin, H, sizeof(H));                 /* LSQ:168 */
+        ok = 1;
+        break;
+      }
+    }
+    if (trace) memcpy(trace + (size_t)it * 16, x0, 16 * sizeof(double));
+    if (!ok) break; /* LSQ:71-74 "lm not converged!!" */
+    converged = is_converged(delta, p); /* LSQ:75 */
+  }
+  for (int i = 0; i < 16; i++) final_T[i] = (float)x0[i]; /* LSQ:78 */
+  if (final_H) memcpy(final_H, Hfin, sizeof(Hfin));
+  if (converged_out) *converged_out = converged;
+  if (nr_iterations_out) *nr_iterations_out = nr_iterations;
+  if (counters) *counters = cnt;
+  free(corr);
+  free(sqd);
+  free(maha);
+  free(geo_w);
+  return 0;
+}
+
+/* ---------------------------------------------------------------- helpers exported for tests */
+void apdo_ldlt6_solve(const double* A, const double* rhs, double* x) { ldlt6_solve(A, rhs, x); }
+void apdo_delta_from_d(const double* d, double* delta) { delta_from_d(d, delta); }
+void apdo_sym3_eigen(const double* A, double* w, double* V) { sym3_eigen(A, w, V); }
+void apdo_sensor_cov(const apdo_params* p, const float* q, double* cov_r) { sensor_cov(p, q, cov_r); }
+void apdo_transform_point_f(const double* T, const float* p, float* q) {
+  float Tf[16];
+  for (int i = 0; i < 16; i++) Tf[i] = (float)T[i];
+  transform_point_f(Tf, p[0], p[1], p[2], q);
+}

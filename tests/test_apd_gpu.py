@@ -1,0 +1,301 @@
+"""GPU parity tests of the APD-GICP path: HIP (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Gates: correspondence and k-NN indices BIT-EXACT; H, b, error relative error <= 1e-9; final transform within
+1e-4 m / 1e-4 rad; plus size-independent properties at the BASELINE sizes (16k x 16k).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+synth = importlib.import_module("go-rio_amd.synth")
+pytestmark = pytest.mark.gpu
+
+H_RTOL = 1e-9
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+
+
+def make(gorio, sx, sl, tx, tl, **params):
+    g = gorio.ApdGicp(**params)
+    g.setInputTarget(tx, tl)
+    g.setInputSource(sx, sl)
+    return g
+
+
+def _pose():
+    T = np.eye(4)
+    T[:3, :3] = synth.rpy_to_matrix([0.1, -0.1, 1.0])
+    T[:3, 3] = [0.2, -0.05, 0.01]
+    return T
+
+
+@pytest.fixture(scope="module")
+def pair2k():
+    return synth.scan_pair(2000, 2300, seed=21)  # ragged sizes: not multiples of 16 / 64 / 256
+
+
+@pytest.mark.parametrize("n", [20, 21, 255, 257, 1000, 2300])
+def test_knn_indices_bit_exact(gpu, gorio, oracle_apd, n):
+    xyz, lab = synth.radar_scan(n, seed=100 + n)
+    g = make(gorio, xyz, lab, xyz, lab)
+    g.calculateCovariances()
+    idx = g.getKnnIndices(0)
+    idx_o, _ = oracle_apd.knn_self(xyz, 20)
+    assert np.array_equal(idx, idx_o)
+
+
+@pytest.mark.parametrize("k", [5, 20, 27, 32])
+def test_knn_other_k(gpu, gorio, oracle_apd, k):
+    xyz, lab = synth.radar_scan(700, seed=7)
+    g = make(gorio, xyz, lab, xyz, lab, k_correspondences=k)
+    g.calculateCovariances()
+    idx_o, _ = oracle_apd.knn_self(xyz, k)
+    assert np.array_equal(g.getKnnIndices(1), idx_o)
+    cov_o = oracle_apd.covariances_from_knn(xyz, idx_o, oracle_apd.REG_PLANE)
+    assert np.allclose(g.getTargetCovariances(), cov_o, rtol=0, atol=1e-9)
+
+
+def test_knn_with_duplicate_points_ties_lowest_index(gpu, gorio, oracle_apd):
+    """Exact duplicates and a regular lattice produce many equal distances: ties must go to the lowest index."""
+    gx, gy = np.meshgrid(np.arange(12, dtype=np.float32), np.arange(12, dtype=np.float32))
+    lattice = np.stack([gx.ravel(), gy.ravel(), np.zeros(144, np.float32)], axis=1)
+    xyz = np.concatenate([lattice, lattice[:40]])  # 40 exact duplicates
+    g = make(gorio, xyz, None, xyz, None, regularization=0)
+    g.calculateCovariances()
+    idx_o, _ = oracle_apd.knn_self(xyz, 20)
+    assert np.array_equal(g.getKnnIndices(0), idx_o)
+
+
+@pytest.mark.parametrize("reg", ["PLANE", "NONE", "MIN_EIG", "NORMALIZED_MIN_EIG", "FROBENIUS"])
+def test_covariances_match_oracle(gpu, gorio, oracle_apd, pair2k, reg):
+    sx, sl = pair2k[0], pair2k[1]
+    code = getattr(oracle_apd, "REG_" + reg)
+    g = make(gorio, sx, sl, sx, sl, regularization=code)
+    g.calculateCovariances()
+    idx_o, _ = oracle_apd.knn_self(sx, 20)
+    cov_o = oracle_apd.covariances_from_knn(sx, idx_o, code)
+    cov = g.getSourceCovariances()
+    assert cov.shape == cov_o.shape
+    if reg in ("NONE", "FROBENIUS"):
+        assert np.allclose(cov, cov_o, rtol=1e-12, atol=1e-15)
+    else:
+        # eigenvector based: error scales with 1 / (relative eigen gap of the raw covariance)
+        raw = oracle_apd.covariances_from_knn(sx, idx_o, oracle_apd.REG_NONE)[:, :3, :3]
+        w = np.linalg.eigvalsh(raw)
+        gap = np.minimum(w[:, 1] - w[:, 0], w[:, 2] - w[:, 1]) / np.maximum(w[:, 2], 1e-300)
+        err = np.abs(cov - cov_o).reshape(len(cov), -1).max(axis=1)
+        assert np.all(err <= 1e-13 / np.maximum(gap, 1e-12) + 1e-12), float(err.max())
+        assert np.median(err) < 1e-13
+
+
+def test_linearize_matches_oracle(gpu, gorio, oracle_apd, pair2k):
+    sx, sl, tx, tl, _ = pair2k
+    p = oracle_apd.launch_params()
+    cs = oracle_apd.calculate_covariances(sx, p)
+    ct = oracle_apd.calculate_covariances(tx, p)
+    g = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, transformation_epsilon=0.1)
+    T = _pose()
+    err, H, b = g.linearize(T)
+    err_o, H_o, b_o, corr_o, sqd_o, maha_o = oracle_apd.linearize(T, sx, sl, tx, tl, cs, ct, p)
+    corr, sqd = g.getCorrespondences()
+    assert np.array_equal(corr, corr_o)  # bit-exact indices, including the -1 rejections
+    assert np.array_equal(sqd, sqd_o)
+    assert (corr < 0).any() and (corr >= 0).sum() > 500
+    assert rel(H, H_o) < H_RTOL and rel(b, b_o) < H_RTOL and abs(err - err_o) / err_o < H_RTOL
+    maha = g.getMahalanobis()
+    m = corr >= 0
+    assert np.allclose(maha[m], maha_o[m], rtol=1e-9, atol=1e-12)
+    assert np.all(maha[~m] == 0)
+    # compute_error at other poses re-uses the stale correspondences (APD:310-346)
+    gw = oracle_apd.geo_weights(cs)
+    for dz in (0.0, 0.3):
+        T2 = T.copy()
+        T2[2, 3] += dz
+        e2 = g.compute_error(T2)
+        e2_o = oracle_apd.compute_error(T2, sx, sl, tx, tl, gw, p, corr_o, maha_o)
+        assert abs(e2 - e2_o) / e2_o < H_RTOL
+
+
+def test_linearize_with_oracle_covariances_injected(gpu, gorio, oracle_apd, pair2k):
+    """setSourceCovariances / setTargetCovariances (APD:138-145): identical covariances in => H, b to rounding."""
+    sx, sl, tx, tl, _ = pair2k
+    p = oracle_apd.launch_params()
+    cs = oracle_apd.calculate_covariances(sx, p)
+    ct = oracle_apd.calculate_covariances(tx, p)
+    g = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0)
+    g.setSourceCovariances(cs)
+    g.setTargetCovariances(ct)
+    iu = np.triu_indices(4)
+    assert np.array_equal(g.getSourceCovariances()[:, iu[0], iu[1]], cs[:, iu[0], iu[1]])  # the upper triangle is what is kept
+    err, H, b = g.linearize(_pose())
+    err_o, H_o, b_o, *_ = oracle_apd.linearize(_pose(), sx, sl, tx, tl, cs, ct, p)
+    assert rel(H, H_o) < 1e-12 and rel(b, b_o) < 1e-11 and abs(err - err_o) / err_o < 1e-12
+
+
+def test_identical_clouds_identity(gpu, gorio):
+    xyz, lab = synth.radar_scan(1500, seed=4)
+    g = make(gorio, xyz, lab, xyz, lab, corr_dist_threshold=2.0)
+    err, H, b = g.linearize(np.eye(4))
+    corr, sqd = g.getCorrespondences()
+    assert np.array_equal(corr, np.arange(1500)) and np.all(sqd == 0)
+    assert err == 0.0 and np.all(b == 0)
+    assert np.all(np.linalg.eigvalsh(H) > 0)
+
+
+def test_all_rejected(gpu, gorio):
+    """Every correspondence beyond the gate: H = b = 0, error = 0 (APD:183-187)."""
+    xyz, lab = synth.radar_scan(300, seed=4)
+    far = xyz + np.float32(1000.0)
+    g = make(gorio, xyz, lab, far, lab, corr_dist_threshold=2.0)
+    err, H, b = g.linearize(np.eye(4))
+    corr, _ = g.getCorrespondences()
+    assert np.all(corr == -1) and err == 0 and not H.any() and not b.any()
+
+
+def test_default_threshold_accepts_everything(gpu, gorio, oracle_apd):
+    """corr_dist_threshold_ defaults to FLT_MAX (APD:23): no rejection."""
+    sx, sl, tx, tl, _ = synth.scan_pair(500, 600, seed=2)
+    g = make(gorio, sx, sl, tx, tl)
+    g.linearize(np.eye(4))
+    corr, _ = g.getCorrespondences()
+    assert np.all(corr >= 0)
+    p = oracle_apd.default_params()
+    cs = oracle_apd.calculate_covariances(sx, p)
+    ct = oracle_apd.calculate_covariances(tx, p)
+    corr_o, _, _ = oracle_apd.update_correspondences(np.eye(4), sx, tx, cs, ct, p)
+    assert np.array_equal(corr, corr_o)
+
+
+@pytest.mark.parametrize("optimizer", ["LM", "GN"])
+def test_align_matches_oracle_c1(gpu, gorio, oracle_apd, pose_err, optimizer):
+    """BASELINE config C1: 5k x 5k pair, shipped launch parameters."""
+    sx, sl, tx, tl, Tgt = synth.scan_pair(5000, 5000, seed=20250704)
+    opt = oracle_apd.OPT_LM if optimizer == "LM" else oracle_apd.OPT_GN
+    p = oracle_apd.launch_params(optimizer=opt)
+    cs = oracle_apd.calculate_covariances(sx, p)
+    ct = oracle_apd.calculate_covariances(tx, p)
+    ro = oracle_apd.align(np.eye(4), sx, sl, tx, tl, cs, ct, p)
+    g = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, transformation_epsilon=0.1, optimizer=opt)
+    r = g.align()
+    te, re = pose_err(ro["T"], r["T"])
+    assert te < 1e-4 and re < 1e-4, (te, re)
+    assert r["converged"] == ro["converged"] and r["nr_iterations"] == ro["nr_iterations"] and r["n_linearize"] == ro["n_linearize"]
+    assert rel(r["H"], ro["H"]) < 1e-6
+    assert g.hasConverged() == ro["converged"]
+
+
+def test_align_tight_epsilon_iteration_trace(gpu, gorio, oracle_apd, pose_err):
+    """Tight epsilons -> many iterations; the final pose still agrees to 1e-4 and the iteration count is identical."""
+    sx, sl, tx, tl, _ = synth.scan_pair(3000, 3000, seed=5, noise_scale=0.1)
+    p = oracle_apd.launch_params(transformation_epsilon=1e-3)
+    cs = oracle_apd.calculate_covariances(sx, p)
+    ct = oracle_apd.calculate_covariances(tx, p)
+    ro = oracle_apd.align(np.eye(4), sx, sl, tx, tl, cs, ct, p)
+    g = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, transformation_epsilon=1e-3)
+    r = g.align()
+    te, re = pose_err(ro["T"], r["T"])
+    assert te < 1e-4 and re < 1e-4
+    assert r["n_linearize"] == ro["n_linearize"] and r["converged"] == ro["converged"]
+
+
+def test_swap_source_and_target(gpu, gorio, oracle_apd, pose_err):
+    """swapSourceAndTarget (APD:89-98) keeps the covariances with their clouds: backward alignment == oracle backward."""
+    sx, sl, tx, tl, _ = synth.scan_pair(1500, 1700, seed=8)
+    p = oracle_apd.launch_params()
+    cs = oracle_apd.calculate_covariances(sx, p)
+    ct = oracle_apd.calculate_covariances(tx, p)
+    g = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, transformation_epsilon=0.1)
+    r_f = g.align()
+    g.swapSourceAndTarget()
+    assert len(g.getSourceCovariances()) == 1700  # covariances travelled with the clouds, not recomputed
+    r_b = g.align()
+    ro_b = oracle_apd.align(np.eye(4), tx, tl, sx, sl, ct, cs, p)
+    te, re = pose_err(ro_b["T"], r_b["T"])
+    assert te < 1e-4 and re < 1e-4
+    ro_f = oracle_apd.align(np.eye(4), sx, sl, tx, tl, cs, ct, p)
+    te, re = pose_err(ro_f["T"], r_f["T"])
+    assert te < 1e-4 and re < 1e-4
+
+
+def test_set_input_invalidates_only_that_cloud(gpu, gorio):
+    """setInputTarget clears only the target covariances (APD:133); clearSource drops the source ones (APD:101-105)."""
+    sx, sl, tx, tl, _ = synth.scan_pair(400, 500, seed=8)
+    g = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0)
+    assert len(g.getSourceCovariances()) == 0 and len(g.getTargetCovariances()) == 0  # stale until first use
+    g.calculateCovariances()
+    assert len(g.getSourceCovariances()) == 400 and len(g.getTargetCovariances()) == 500
+    g.setInputTarget(tx[:450], tl[:450])
+    assert len(g.getSourceCovariances()) == 400 and len(g.getTargetCovariances()) == 0
+    g.clearSource()
+    assert len(g.getSourceCovariances()) == 0
+    with pytest.raises(gorio.GorioError):
+        g.align()  # no source any more
+
+
+def test_error_conventions(gpu, gorio):
+    g = gorio.ApdGicp()
+    with pytest.raises(gorio.GorioError):
+        g.align()  # nothing set
+    xyz, lab = synth.radar_scan(10, seed=1)
+    g.setInputSource(xyz, lab)
+    g.setInputTarget(xyz, lab)
+    with pytest.raises(gorio.GorioError):
+        g.align()  # fewer points than k: undefined in the reference (APD:366-369), refused here
+    with pytest.raises(gorio.GorioError):
+        g.set_params(k_correspondences=33)
+    with pytest.raises(gorio.GorioError):
+        g.set_params(regularization=7)  # the reference abort()s (APD:389-391)
+    with pytest.raises(gorio.GorioError):
+        g.compute_error(np.eye(4))  # no correspondences yet
+
+
+def test_batch_equals_single(gpu, gorio, pose_err):
+    """align_batch advances independent pairs in lock-step; every pair must equal its own single align bit for bit."""
+    pairs = [synth.scan_pair(900 + 37 * q, 1000 + 91 * q, seed=40 + q) for q in range(5)]
+    objs = [make(gorio, *pr[:4], corr_dist_threshold=2.0, transformation_epsilon=0.05) for pr in pairs]
+    singles = [o.align() for o in objs]
+    objs2 = [make(gorio, *pr[:4], corr_dist_threshold=2.0, transformation_epsilon=0.05) for pr in pairs]
+    batch = gorio.align_batch(objs2)
+    for s, b in zip(singles, batch):
+        assert np.array_equal(s["T"], b["T"]) and s["n_linearize"] == b["n_linearize"] and s["converged"] == b["converged"]
+    assert len({b["n_linearize"] for b in batch}) > 1  # the pairs really stop at different iterations
+
+
+def test_transform_source_and_fitness(gpu, gorio, oracle_apd):
+    sx, sl, tx, tl, T = synth.scan_pair(800, 900, seed=12)
+    g = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0)
+    out = g.transformSource(T.astype(np.float32))
+    import ctypes as C
+
+    q = np.zeros(3, np.float32)
+    Td = T.astype(np.float32).astype(np.float64)
+    for i in (0, 17, 799):
+        oracle_apd.lib().apdo_transform_point_f(Td.ctypes.data_as(C.POINTER(C.c_double)), sx[i].ctypes.data_as(C.POINTER(C.c_float)), q.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(out[i], q)
+    score, inl = g.getFitnessScore(T.astype(np.float32))
+    p = oracle_apd.default_params()
+    z = np.zeros((900, 4, 4))
+    corr_o, sqd_o, _ = oracle_apd.update_correspondences(Td, sx, tx, np.zeros((800, 4, 4)), z, p)
+    assert score == pytest.approx(float(np.mean(sqd_o.astype(np.float64))), rel=1e-12)
+    assert inl == pytest.approx(float(np.mean(sqd_o.astype(np.float64) < 4.0)), rel=1e-12)
+
+
+def test_16k_properties(gpu, gorio, pose_err):
+    """BASELINE size (16 384 x 16 384): size-independent properties instead of an O(n^2) oracle run.
+    (1) identity on identical clouds; (2) a rigidly moved copy is recovered to 1e-4; (3) H is symmetric PSD;
+    (4) the error never increases over accepted LM steps (monotone by construction of LSQ:156-170)."""
+    xyz, lab = synth.radar_scan(16384, seed=99)
+    g = make(gorio, xyz, lab, xyz, lab, corr_dist_threshold=2.0, transformation_epsilon=1e-4, rotation_epsilon=1e-5)
+    err, H, b = g.linearize(np.eye(4))
+    corr, sqd = g.getCorrespondences()
+    assert np.array_equal(corr, np.arange(16384)) and err == 0 and not b.any()
+    assert np.allclose(H, H.T) and np.all(np.linalg.eigvalsh(H) > 0)
+    T = synth.gt_transform([0.3, -0.2, 0.05], [0.2, 0.1, 1.0])
+    moved = (xyz.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    g2 = make(gorio, xyz, lab, moved, lab, corr_dist_threshold=2.0, transformation_epsilon=1e-5, rotation_epsilon=1e-6)
+    r = g2.align()
+    te, re = pose_err(T, r["T"])
+    assert r["converged"] and te < 1e-4 and re < 1e-4, (te, re)
