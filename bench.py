@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Go-RIO hot path on MI355X (contract: see the task statement / DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  workload c4 (default; BASELINE.json configs[3]): 64 scan pairs of 16 384 x 16 384 synthetic radar points, each
+      setInputTarget + setInputSource (device-to-device) + k-NN covariance estimation + a Gauss-Newton loop of 20 fixed
+      iterations (convergence test disabled, as SURVEY 8d prescribes for the throughput configs), plus 64 GP
+      pre-integration windows (1 s @ 200 Hz) when the UGPM back end is present.
+  workload c3 (configs[2]): one 16 384-pt scan against a 100 000-pt local map, 20 iterations.
+metric = APD-GICP linearisations per second (one unit = one linearize(): correspondence search + Mahalanobis + H/b/error
+reduction for one pair at one pose); GP windows/s is reported beside it.  Multi-GPU: every rank owns its own batch (weak
+scaling, no data-path collective), value = all units / max-over-ranks time.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 vector == f32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c3"])
+    ap.add_argument("--pairs", type=int, default=64)
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--search", default="brute", choices=["brute", "pruned"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=1)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    gorio = importlib.import_module("go-rio_amd")
+    synth = gorio.synth
+    GN = 0
+    n = args.points
+    params = dict(corr_dist_threshold=2.0, max_iterations=args.iters, optimizer=GN, rotation_epsilon=0.0, transformation_epsilon=0.0,
+                  search=1 if args.search == "pruned" else 0)
+
+    # ---- synthetic inputs, generated on the host then made resident in HBM (torch is only the allocator here)
+    seed0 = synth.BASE_SEED + 3 + 1000 * rank
+    pairs = []
+    if args.workload == "c4":
+        n_pairs, m = args.pairs, n
+        for q in range(n_pairs):
+            pairs.append(synth.scan_pair(n, m, seed=seed0 + q))
+    else:
+        n_pairs, m = 1, 100000
+        sx, sl = synth.radar_scan(n, seed=seed0)
+        tx, tl = synth.local_map(m, seed=seed0 + 1)
+        pairs.append((sx, sl, tx, tl, synth.gt_transform()))
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    resident = []
+    for sx, sl, tx, tl, _ in pairs:
+        resident.append(dict(
+            s=[to_dev(sx[:, 0]), to_dev(sx[:, 1]), to_dev(sx[:, 2]), to_dev(sl)],
+            t=[to_dev(tx[:, 0]), to_dev(tx[:, 1]), to_dev(tx[:, 2]), to_dev(tl)], n=sx.shape[0], m=tx.shape[0]))
+    torch.cuda.synchronize()
+    objs = [gorio.ApdGicp(device=local_rank, **params) for _ in range(n_pairs)]
+    objs[0].setProfiling(True)
+
+    have_ugpm = hasattr(gorio, "ugpm_preint_batch")
+    windows = None
+    if have_ugpm and args.workload == "c4":
+        windows = [synth.imu_window(seed=seed0 + 500 + q) for q in range(n_pairs)]
+
+    def step():
+        for o, r in zip(objs, resident):  # setInputTarget / setInputSource from HBM-resident buffers (invalidates covariances)
+            o.setInputTargetDevice(*[t.data_ptr() for t in r["t"]], r["m"])
+            o.setInputSourceDevice(*[t.data_ptr() for t in r["s"]], r["n"])
+        res = gorio.align_batch(objs)
+        nwin = 0
+        if windows is not None:
+            gorio.ugpm_preint_batch(windows, device=local_rank)
+            nwin = len(windows)
+        return sum(r["n_linearize"] for r in res), nwin
+
+    for _ in range(args.warmup):
+        step()
+    objs[0].setProfiling(True)  # reset the stage clocks: they now cover exactly the timed region
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    units = wins = 0
+    for _ in range(args.steps):
+        u, w = step()
+        units += u
+        wins += w
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cnt = torch.tensor([units, wins], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        units, wins = int(cnt[0].item()), int(cnt[1].item())
+
+    stage_s, stage_n = objs[0].getStageTimes()
+
+    if rank == 0:
+        # dominant kernel: nn_search_kernel.  Algorithmic work per launch = 8 flop per (source, target) pair evaluated by one
+        # batched launch (flops = 8 N M per linearisation; the 700 N tail belongs to linearize_kernel).
+        nn_avg = stage_s[1] / max(stage_n[1], 1)
+        flops_per_launch = 8.0 * sum(r["n"] * r["m"] for r in resident)
+        achieved = flops_per_launch / nn_avg / 1e12 if nn_avg > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(f"nn_search_kernel:{args.workload}:{args.search}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "APD-GICP GN iters/sec on 16k-pt scans + GP-preint windows/sec",
+            "value": units / dt,
+            "unit": "linearisations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 search / f64 accumulate",
+            "data": "synthetic",
+            "config": {
+                "workload": ("C4: 64 scan pairs 16384x16384 (+64 GP windows 1 s @ 200 Hz when present), k-NN covariances + 20 fixed GN iterations per pair"
+                             if args.workload == "c4" else "C3: 16384-pt scan vs 100000-pt local map, 20 fixed GN iterations"),
+                "pairs_per_gpu": n_pairs, "source_points": n, "target_points": m, "iterations": args.iters, "optimizer": "GN (convergence test disabled)",
+                "search": args.search, "parallelism": f"batch shard x{world} (no collective)"},
+            "gp_windows_per_s": (wins / dt) if wins else None,
+            "aligns_per_s": n_pairs * world * args.steps / dt,
+            "stage_seconds": {"knn_cov": stage_s[0], "nn_search": stage_s[1], "linearize": stage_s[2], "solve": stage_s[3]},
+            "stage_launches": {"knn_cov": stage_n[0], "nn_search": stage_n[1], "linearize": stage_n[2], "solve": stage_n[3]},
+            "roofline": {"bound": "mfma", "kernel": "nn_search_kernel", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+                         "note": "FP32 vector-ALU bound (157.3 TFLOP/s: FP32 vector peak == f32 MFMA peak on MI355X); 8 flop per point pair, un-fused by design (bit-exact indices)",
+                         "avg_launch_ms": 1e3 * nn_avg},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pairs[: args.cpu_sample_pairs], args)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def usable_cores():
+    """Host cores this process may actually use: the cgroup CPU quota when there is one (the GPU box grants 16 of 256), else
+    the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(sample_pairs, args):
+    """The oracle (a port: the reference itself cannot be compiled here) timed on the host cores of this box on a bounded
+    sample of the same workload: covariances + the same fixed-iteration GN loop for `len(sample_pairs)` pairs."""
+    import oracle
+    from oracle import apd as oa
+
+    oracle.build()
+    p = oa.launch_params(max_iterations=args.iters, optimizer=oa.OPT_GN, rotation_epsilon=0.0, transformation_epsilon=0.0)
+    cores = usable_cores()
+    p.num_threads = cores
+    t0 = time.perf_counter()
+    units = 0
+    for sx, sl, tx, tl, _ in sample_pairs:
+        cs = oa.calculate_covariances(sx, p)
+        ct = oa.calculate_covariances(tx, p)
+        r = oa.align(np.eye(4), sx, sl, tx, tl, cs, ct, p)
+        units += r["n_linearize"]
+    dt = time.perf_counter() - t0
+    return {"value": units / dt, "unit": "linearisations/s", "cores": cores, "kind": "port",
+            "sample": f"{len(sample_pairs)} pair(s) of the same workload ({sample_pairs[0][0].shape[0]} x {sample_pairs[0][2].shape[0]} points), "
+                      f"covariances + {args.iters} GN iterations, OpenMP brute-force search on {cores} threads, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -63,7 +63,9 @@ struct gorio_apd {
   bool profiling = false;
   double stage_s[4] = {0, 0, 0, 0};
   int stage_n[4] = {0, 0, 0, 0};
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  struct EvPair { hipEvent_t start, stop; int stage; };
+  std::vector<EvPair> ev_pool;
+  size_t ev_used = 0;
 };
 
 namespace {
@@ -187,24 +189,39 @@ ApdConsts make_consts(const gorio_apd_params& p) {
   return c;
 }
 
+// Stage timing with HIP events on the launch stream.  Events are only RECORDED while kernels are being enqueued (no host
+// synchronisation inside the loop); resolve_stage_events() turns them into seconds after the stream has drained.
 struct StageTimer {
   gorio_apd* h;
-  int stage;
   bool on;
-  StageTimer(gorio_apd* h_, int s) : h(h_), stage(s), on(h_->profiling) {
-    if (on) hipEventRecord(h->ev0, h->stream);
+  size_t slot;
+  StageTimer(gorio_apd* h_, int s) : h(h_), on(h_->profiling), slot(0) {
+    if (!on) return;
+    if (h->ev_used == h->ev_pool.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+      h->ev_pool.push_back({a, b, s});
+    }
+    slot = h->ev_used++;
+    h->ev_pool[slot].stage = s;
+    hipEventRecord(h->ev_pool[slot].start, h->stream);
   }
   ~StageTimer() {
-    if (on) {
-      hipEventRecord(h->ev1, h->stream);
-      hipEventSynchronize(h->ev1);
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, h->ev0, h->ev1);
-      h->stage_s[stage] += ms * 1e-3;
-      h->stage_n[stage] += 1;
-    }
+    if (on) hipEventRecord(h->ev_pool[slot].stop, h->stream);
   }
 };
+
+void resolve_stage_events(gorio_apd* h) {
+  if (!h->profiling) return;
+  for (size_t q = 0; q < h->ev_used; ++q) {
+    float ms = 0.f;
+    if (hipEventSynchronize(h->ev_pool[q].stop) == hipSuccess && hipEventElapsedTime(&ms, h->ev_pool[q].start, h->ev_pool[q].stop) == hipSuccess) {
+      h->stage_s[h->ev_pool[q].stage] += ms * 1e-3;
+      h->stage_n[h->ev_pool[q].stage] += 1;
+    }
+  }
+  h->ev_used = 0;
+}
 
 // covariance estimation for a list of clouds on lead's stream
 int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*>>& todo) {
@@ -422,6 +439,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     HIP_TRY(lead, hipMemcpyAsync(hs[q]->d_state, lead->d_states_batch + q, sizeof(PairState), hipMemcpyDeviceToDevice, lead->stream));
   }
   HIP_TRY(lead, hipStreamSynchronize(lead->stream));
+  resolve_stage_events(lead);
   return GORIO_OK;
 }
 
@@ -470,7 +488,7 @@ int gorio_apd_create(gorio_apd_t** out, int device) {
   h->device = device;
   gorio_apd_default_params(&h->params);
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&h->d_state, sizeof(PairState)) != hipSuccess ||
-      hipMalloc(&h->d_fit, sizeof(double) * 4) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+      hipMalloc(&h->d_fit, sizeof(double) * 4) != hipSuccess) {
     delete h;
     return GORIO_ERR_NO_DEVICE;
   }
@@ -486,8 +504,7 @@ void gorio_apd_destroy(gorio_apd_t* h) {
   free_cloud(h->tgt);
   hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
   hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_fit);
-  if (h->ev0) hipEventDestroy(h->ev0);
-  if (h->ev1) hipEventDestroy(h->ev1);
+  for (auto& e : h->ev_pool) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -603,6 +620,7 @@ int gorio_apd_calculate_covariances(gorio_apd_t* h) {
   int rc = run_covariances(h, todo);
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  resolve_stage_events(h);
   return GORIO_OK;
 }
 
