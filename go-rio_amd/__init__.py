@@ -29,3 +29,4 @@ def build(force: bool = False) -> str:
 
 from . import synth  # noqa: E402  (pure-numpy synthetic inputs, no GPU)
 from .apd import ApdGicp, ApdParams, GorioError, align_batch, load_library  # noqa: E402
+from .ugpm import PreintOption, PreintPrior, VelPreintegration, ugpm_preint_batch, ugpm_stage_times  # noqa: E402

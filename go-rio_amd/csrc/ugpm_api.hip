@@ -1,0 +1,372 @@
+// ugpm_api.hip -- host side of the UGPM C ABI (include/gorio_ugpm.h): window bookkeeping (state time line, sample slicing:
+// preint.h:766-811), device workspace, kernel sequencing of ugpm_kernels.hip.  No numerics happen on the host and there is no
+// CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/gorio_ugpm.h"
+#include "ugpm_kernels.hip"
+
+using namespace gorio;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local double g_stage_s[5] = {0, 0, 0, 0, 0};
+thread_local int g_stage_n[5] = {0, 0, 0, 0, 0};
+
+struct Ctx {  // per-thread, per-device cached buffers
+  int device = -1;
+  hipStream_t stream = nullptr;
+  double* ws = nullptr;
+  size_t ws_cap = 0;
+  UgpmWin* d_wins = nullptr;
+  int wins_cap = 0;
+  int* d_ints = nullptr;  // per window: lmi[16] + status[1] -> 17 ints
+  double* d_diag = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<int> ev_stage;
+};
+thread_local Ctx g_ctx;
+
+int ufail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define UHIP(expr)                                                                                              \
+  do {                                                                                                          \
+    hipError_t e_ = (expr);                                                                                     \
+    if (e_ != hipSuccess) return ufail(GORIO_UGPM_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct HostWin {
+  int g0 = 0, G = 0, v0 = 0, V = 0, S = 0;
+  double state_freq = 0;
+  std::vector<double> state_t;
+  int status = 0;
+  size_t ws_doubles = 0;
+};
+
+// GyroVelData::get(from, to): samples with from < t < to, scanning until the first t >= to (types.h:187-223)
+void slice(const double* t, int n, double from, double to, int& i0, int& cnt) {
+  i0 = 0;
+  cnt = 0;
+  if (from >= to || n <= 0) return;
+  bool started = false;
+  for (int i = 0; i < n; ++i) {
+    if (t[i] > from) {
+      if (t[i] < to) {
+        if (!started) {
+          i0 = i;
+          started = true;
+        }
+        cnt++;
+      } else {
+        break;
+      }
+    }
+  }
+}
+
+// carve one window's slab; returns the number of doubles used (called once with base == nullptr for sizing)
+size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* base) {
+  double* p = base;
+  auto take = [&](size_t cnt) { double* r = p; p += cnt; return r; };
+  const size_t S = h.S, G = h.G, V = h.V, n = 3 * S, mrot = 3 * S + 3 * G, mvel = 3 * V + 3 * S, mc = 3 * G + 3 * V, nc = 6 * S;
+  // inputs first, contiguous: gyr_t, gyr SoA, vel_t, vel SoA, infer_t, state_t (uploaded with one copy)
+  u.gyr_t = take(G); u.gyr = take(3 * G); u.vel_t = take(V); u.vel = take(3 * V); u.infer_t = take(w.n_infer); u.state_t = take(S);
+  u.Rq = take(5 * 2 * S * 9); u.Rstart = take(5 * 9); u.velr = take(3 * V); u.dp = take(2 * S * 3); u.r0 = take(5 * S * 3); u.r1 = take(5 * S * 3);
+  u.s_dr = take(3 * S); u.s_vel = take(3 * S); u.hyper = take(24);
+  u.d_r_dt_local = take(S * 3); u.d_r_dt_local_shift = take(S * 3); u.delta_r_time = take(S * 3); u.delta_r_bw = take(3 * S * 3); u.d_r_bw_local_shift = take(3 * S * 3);
+  u.Kinv = take(6 * S * S); u.KKinv = take(6 * S * S); u.KintKinv = take(3 * S * S); u.var = take(6 * S); u.wgp = take(6 * S); u.sstd = take(6 * S);
+  u.KsKinv = take(3 * G * S); u.KsIntKinv = take(3 * G * S); u.KgyrIntKinv = take(3 * V * S); u.KvelKinv = take(3 * V * S);
+  u.Jrot = take(mrot * n); u.Jvel = take(mvel * n); u.res = take(std::max(mrot, mvel)); u.res_new = take(std::max(mrot, mvel));
+  u.JtJ = take(n * n); u.lhs = take(n * n); u.lmv = take(8 * n); u.sample_tmp = take(std::max(G, V) * 24);
+  if (w.correlate) { u.Jc = take(mc * nc); u.Ac = take(nc * nc); u.Linv = take(nc * nc); }
+  u.dsc = take(nc);
+  u.alpha = take(6 * S); u.state_r = take(3 * S); u.d_state_bw = take(3 * S * 3); u.d_d_r_dt = take(3 * S); u.d_vel_bv = take(3 * S * 3); u.d_vel_bw = take(3 * S * 3);
+  u.d_vel_dt = take(3 * S); u.out = take((size_t)w.n_infer * 83); u.lmc = take(16);
+  return ((size_t)(p - base) + 31) / 32 * 32;
+}
+
+struct Stage {
+  Ctx& c;
+  bool on;
+  Stage(Ctx& c_, int s) : c(c_), on(true) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    c.ev.emplace_back(a, b);
+    c.ev_stage.push_back(s);
+    hipEventRecord(a, c.stream);
+  }
+  ~Stage() {
+    if (on) hipEventRecord(c.ev.back().second, c.stream);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+void gorio_ugpm_default_window(gorio_ugpm_window* w) {
+  if (!w) return;
+  std::memset(w, 0, sizeof(*w));
+  w->type = GORIO_UGPM_TYPE_UGPM;  // types.h:288
+  w->min_freq = 500;                // types.h:287
+  w->quantum = -1;                  // types.h:289
+  w->state_freq = 50.0;             // types.h:290
+  w->correlate = 1;                 // types.h:291
+  w->overlap = 8;                   // preint.h:19
+  w->vel_bias_std = 0.3;            // preint.h:55
+  w->gyr_bias_std = 0.03;
+}
+
+const char* gorio_ugpm_last_error(void) { return g_err.c_str(); }
+
+int gorio_ugpm_get_stage_times(double seconds[5], int counts[5]) {
+  for (int i = 0; i < 5; ++i) {
+    if (seconds) seconds[i] = g_stage_s[i];
+    if (counts) counts[i] = g_stage_n[i];
+  }
+  return 0;
+}
+
+int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gorio_ugpm_meas* out, gorio_ugpm_diag* diag, int device) {
+  if (!windows || n_windows <= 0 || !out) return ufail(GORIO_UGPM_ERR_INVALID, "gorio_ugpm_preint_batch: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ufail(GORIO_UGPM_ERR_NO_DEVICE, "no usable HIP device (no CPU fallback exists)");
+  if (device < 0 || device >= ndev) return ufail(GORIO_UGPM_ERR_INVALID, "bad device ordinal");
+  UHIP(hipSetDevice(device));
+  Ctx& c = g_ctx;
+  if (c.device != device) {
+    if (c.stream) hipStreamDestroy(c.stream);
+    hipFree(c.ws); hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag);
+    c = Ctx();
+    c.device = device;
+    UHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  }
+  for (int i = 0; i < 5; ++i) { g_stage_s[i] = 0; g_stage_n[i] = 0; }
+
+  // ---- host bookkeeping per window (preint.h:1532-1556, 766-811): no numerics beyond the state time line
+  std::vector<HostWin> hw(n_windows);
+  size_t total_doubles = 0;
+  int total_infer = 0, max_infer = 0, max_S = 0;
+  int first_error = 0;
+  std::string first_error_msg;
+  auto win_fail = [&](int i, int code, const std::string& m) {
+    hw[i].status = code;
+    if (!first_error) {
+      first_error = code;
+      first_error_msg = "window " + std::to_string(i) + ": " + m;
+    }
+  };
+  for (int i = 0; i < n_windows; ++i) {
+    const gorio_ugpm_window& w = windows[i];
+    HostWin& h = hw[i];
+    total_infer += std::max(0, w.n_infer);
+    max_infer = std::max(max_infer, w.n_infer);
+    if (!w.gyr_t || !w.gyr || !w.vel_t || !w.vel || !w.infer_t || w.n_infer <= 0) { win_fail(i, GORIO_UGPM_ERR_INVALID, "null pointers or no inference time"); continue; }
+    if (w.quantum >= 0) { win_fail(i, GORIO_UGPM_ERR_UNSUPPORTED, "chunked pre-integration (opt.quantum > 0, preint.h:1584-1702) is not supported; Go-RIO uses quantum = -1"); continue; }
+    if (w.type != GORIO_UGPM_TYPE_UGPM) { win_fail(i, GORIO_UGPM_ERR_UNSUPPORTED, "only type = UGPM is offloaded (LPM is used internally for initialisation)"); continue; }
+    if (w.n_gyr < 2 || w.n_vel < 2) { win_fail(i, GORIO_UGPM_ERR_RANGE, "InterpolateLinear: this function need at least 2 data points to interpolate"); continue; }
+    const double vel_freq = (w.n_vel - 1) / (w.vel_t[w.n_vel - 1] - w.vel_t[0]);
+    const double gyr_freq = (w.n_gyr - 1) / (w.gyr_t[w.n_gyr - 1] - w.gyr_t[0]);
+    const double duration = *std::max_element(w.infer_t, w.infer_t + w.n_infer) - w.start_t;  // preint.h:1544-1552
+    if (!(duration > 0.0) || !std::isfinite(duration)) { win_fail(i, GORIO_UGPM_ERR_ARGUMENT, "inference time is not after start_t"); continue; }
+    double sf = std::max(w.state_freq, 5.0 / duration);  // preint.h:770-771
+    sf = std::min(sf, std::min(vel_freq, gyr_freq));
+    h.state_freq = sf;
+    h.S = (int)(std::ceil(duration * sf) + (2 * w.overlap));  // preint.h:775
+    if (h.S < 2 * w.overlap + 1 || h.S > 160) { win_fail(i, GORIO_UGPM_ERR_UNSUPPORTED, "number of GP states outside [2 overlap + 1, 160]"); continue; }
+    h.state_t.resize(h.S);
+    const double t0 = w.start_t - (((double)w.overlap) / sf);
+    for (int k = 0; k < h.S; ++k) h.state_t[k] = t0 + ((double)k) / sf;  // preint.h:777-783
+    if (!(h.state_t[0] <= h.state_t.back())) { win_fail(i, GORIO_UGPM_ERR_ARGUMENT, "The argument of GyroVelData::Get are not consistent"); continue; }
+    slice(w.gyr_t, w.n_gyr, h.state_t[0], h.state_t.back(), h.g0, h.G);  // preint.h:789
+    slice(w.vel_t, w.n_vel, h.state_t[0], h.state_t.back(), h.v0, h.V);
+    if (h.G < 2 || h.V < 2) { win_fail(i, GORIO_UGPM_ERR_RANGE, "fewer than 2 gyro / velocity samples inside the state window"); continue; }
+    max_S = std::max(max_S, h.S);
+    UgpmWin dummy;
+    h.ws_doubles = carve(w, h, dummy, nullptr);
+    total_doubles += h.ws_doubles;
+  }
+  if (total_doubles > c.ws_cap) {
+    hipFree(c.ws);
+    c.ws = nullptr;
+    c.ws_cap = 0;
+    UHIP(hipMalloc(&c.ws, sizeof(double) * total_doubles));
+    c.ws_cap = total_doubles;
+  }
+  if (n_windows > c.wins_cap) {
+    hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag);
+    c.d_wins = nullptr; c.d_ints = nullptr; c.d_diag = nullptr;
+    UHIP(hipMalloc(&c.d_wins, sizeof(UgpmWin) * n_windows));
+    UHIP(hipMalloc(&c.d_ints, sizeof(int) * 17 * n_windows));
+    UHIP(hipMalloc(&c.d_diag, sizeof(double) * 4 * n_windows));
+    c.wins_cap = n_windows;
+  }
+
+  // ---- carve the workspace, stage the inputs
+  std::vector<UgpmWin> dw(n_windows);
+  std::vector<double> stage_in;
+  std::vector<int> ints(17 * (size_t)n_windows, 0);
+  double* base = c.ws;
+  std::vector<std::pair<double*, size_t>> uploads;  // (device dst, offset into stage_in) with lengths kept alongside
+  std::vector<size_t> upload_len;
+  for (int i = 0; i < n_windows; ++i) {
+    const gorio_ugpm_window& w = windows[i];
+    HostWin& h = hw[i];
+    UgpmWin& u = dw[i];
+    std::memset(&u, 0, sizeof(u));
+    u.lmi = c.d_ints + 17 * (size_t)i;
+    u.status = c.d_ints + 17 * (size_t)i + 16;
+    ints[17 * (size_t)i + 16] = h.status;
+    u.n_infer = std::max(0, w.n_infer);
+    if (h.status != 0) {
+      u.out = nullptr;
+      continue;
+    }
+    carve(w, h, u, base);
+    const size_t S = h.S, G = h.G, V = h.V;
+    double* d_gt = const_cast<double*>(u.gyr_t);
+    u.G = h.G; u.V = h.V; u.S = h.S;
+    u.correlate = w.correlate ? 1 : 0; u.overlap = w.overlap;
+    u.start_t = w.start_t; u.state_freq = h.state_freq; u.gyr_var = w.gyr_var; u.vel_var = w.vel_var;
+    for (int a = 0; a < 3; ++a) { u.gyr_bias[a] = w.gyr_bias[a]; u.vel_bias[a] = w.vel_bias[a]; }
+    u.vel_bias_std = w.vel_bias_std; u.gyr_bias_std = w.gyr_bias_std;
+    base += h.ws_doubles;
+    // stage inputs contiguously: gyr_t, gyr SoA, vel_t, vel SoA, infer_t, state_t (they are contiguous in the slab)
+    const size_t off = stage_in.size();
+    stage_in.resize(off + G + 3 * G + V + 3 * V + (size_t)w.n_infer + S);
+    double* s = stage_in.data() + off;
+    for (size_t k = 0; k < G; ++k) s[k] = w.gyr_t[h.g0 + k];
+    s += G;
+    for (int a = 0; a < 3; ++a)
+      for (size_t k = 0; k < G; ++k) s[a * G + k] = w.gyr[3 * (size_t)(h.g0 + k) + a];
+    s += 3 * G;
+    for (size_t k = 0; k < V; ++k) s[k] = w.vel_t[h.v0 + k];
+    s += V;
+    for (int a = 0; a < 3; ++a)
+      for (size_t k = 0; k < V; ++k) s[a * V + k] = w.vel[3 * (size_t)(h.v0 + k) + a];
+    s += 3 * V;
+    for (int k = 0; k < w.n_infer; ++k) s[k] = w.infer_t[k];
+    s += w.n_infer;
+    for (size_t k = 0; k < S; ++k) s[k] = h.state_t[k];
+    uploads.emplace_back(d_gt, off);
+    upload_len.push_back(G + 3 * G + V + 3 * V + (size_t)w.n_infer + S);
+  }
+  for (size_t q = 0; q < uploads.size(); ++q)
+    UHIP(hipMemcpyAsync(uploads[q].first, stage_in.data() + uploads[q].second, sizeof(double) * upload_len[q], hipMemcpyHostToDevice, c.stream));
+  UHIP(hipMemcpyAsync(c.d_wins, dw.data(), sizeof(UgpmWin) * n_windows, hipMemcpyHostToDevice, c.stream));
+  UHIP(hipMemcpyAsync(c.d_ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice, c.stream));
+  UHIP(hipStreamSynchronize(c.stream));  // staging vectors are pageable
+
+  const int nw = n_windows;
+  const int max_G = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.G); return m; }();
+  const int max_V = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.V); return m; }();
+  if (max_S > 0) {
+    const int tiles_n = (3 * max_S + 63) / 64, tiles_c = (6 * max_S + 63) / 64;
+    {
+      Stage st(c, 0);
+      ug::lpm_init_kernel<<<nw, 320, 0, c.stream>>>(c.d_wins);
+    }
+    {
+      Stage st(c, 1);
+      ug::gram_kernel<<<dim3(6, nw), 256, 0, c.stream>>>(c.d_wins);
+      ug::cross_kernel<<<dim3(12, nw, (std::max(max_G, max_V) + 7) / 8), 256, 0, c.stream>>>(c.d_wins);
+    }
+    {
+      Stage st(c, 2);  // state correlation at the LPM-initialised state (a side thread in the reference, preint.h:939)
+      ug::corr_jac_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
+      ug::ata_kernel<<<dim3(tiles_c, tiles_c, nw), 256, 0, c.stream>>>(c.d_wins, 2);
+      ug::corr_factor_kernel<<<nw, 1024, 0, c.stream>>>(c.d_wins);
+    }
+    std::vector<int> flags(17 * (size_t)nw);
+    for (int problem = 0; problem < 2; ++problem) {  // ceres::Solve #1 (rotation) and #2 (velocity), preint.h:943-967
+      Stage st(c, 3);
+      ug::lm_begin_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, problem);
+      if (problem == 0) ug::rot_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 2);
+      else ug::vel_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 2);
+      ug::ata_kernel<<<dim3(tiles_n, tiles_n, nw), 256, 0, c.stream>>>(c.d_wins, problem);
+      for (int it = 0; it <= 51; ++it) {
+        ug::lm_step_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
+        if (problem == 0) ug::rot_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 0);
+        else ug::vel_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 0);
+        ug::lm_decide_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
+        if (problem == 0) ug::rot_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 1);
+        else ug::vel_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 1);
+        ug::ata_kernel<<<dim3(tiles_n, tiles_n, nw), 256, 0, c.stream>>>(c.d_wins, problem);
+        if ((it & 1) == 1) {  // poll the done flags every other iteration
+          UHIP(hipMemcpyAsync(flags.data(), c.d_ints, sizeof(int) * flags.size(), hipMemcpyDeviceToHost, c.stream));
+          UHIP(hipStreamSynchronize(c.stream));
+          bool all = true;
+          for (int i = 0; i < nw; ++i) all = all && (flags[17 * (size_t)i + 1] || flags[17 * (size_t)i + 16] != 0);
+          if (all) break;
+        }
+      }
+      ug::lm_end_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, problem, c.d_diag);
+    }
+    {
+      Stage st(c, 4);
+      ug::finish_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
+      ug::infer_kernel<<<dim3(std::max(1, max_infer), nw), 256, 0, c.stream>>>(c.d_wins);
+    }
+    UHIP(hipGetLastError());
+  }
+  // ---- results
+  std::vector<int> fin(17 * (size_t)nw);
+  std::vector<double> dg(4 * (size_t)nw);
+  UHIP(hipMemcpyAsync(fin.data(), c.d_ints, sizeof(int) * fin.size(), hipMemcpyDeviceToHost, c.stream));
+  UHIP(hipMemcpyAsync(dg.data(), c.d_diag, sizeof(double) * dg.size(), hipMemcpyDeviceToHost, c.stream));
+  size_t rec = 0;
+  for (int i = 0; i < nw; ++i) {
+    const int ni = std::max(0, windows[i].n_infer);
+    if (hw[i].status == 0) {
+      UHIP(hipMemcpyAsync(reinterpret_cast<double*>(out) + rec * 83, dw[i].out, sizeof(double) * 83 * ni, hipMemcpyDeviceToHost, c.stream));
+    } else {
+      double* o = reinterpret_cast<double*>(out) + rec * 83;
+      for (size_t k = 0; k < (size_t)ni * 83; ++k) o[k] = std::numeric_limits<double>::quiet_NaN();
+    }
+    rec += ni;
+  }
+  UHIP(hipStreamSynchronize(c.stream));
+  for (size_t q = 0; q < c.ev.size(); ++q) {
+    float ms = 0.f;
+    if (hipEventSynchronize(c.ev[q].second) == hipSuccess && hipEventElapsedTime(&ms, c.ev[q].first, c.ev[q].second) == hipSuccess) {
+      g_stage_s[c.ev_stage[q]] += ms * 1e-3;
+      g_stage_n[c.ev_stage[q]] += 1;
+    }
+    hipEventDestroy(c.ev[q].first);
+    hipEventDestroy(c.ev[q].second);
+  }
+  c.ev.clear();
+  c.ev_stage.clear();
+  for (int i = 0; i < nw; ++i) {
+    int st = hw[i].status != 0 ? hw[i].status : fin[17 * (size_t)i + 16];
+    if (st != 0 && hw[i].status == 0 && !first_error) {
+      first_error = st;
+      first_error_msg = "window " + std::to_string(i) + (st == GORIO_UGPM_ERR_NUMERIC ? ": Cholesky factorisation met a non-positive pivot" : ": LPM Partial: the start_time is not in the data domain");
+    }
+    if (diag) {
+      gorio_ugpm_diag& d = diag[i];
+      d.nb_state = hw[i].S; d.nb_gyr = hw[i].G; d.nb_vel = hw[i].V;
+      d.iters_rot = (int)dg[4 * (size_t)i + 0]; d.cost_rot = dg[4 * (size_t)i + 1];
+      d.iters_vel = (int)dg[4 * (size_t)i + 2]; d.cost_vel = dg[4 * (size_t)i + 3];
+      d.status = st; d.state_freq = hw[i].state_freq;
+    }
+  }
+  if (first_error) return ufail(first_error, first_error_msg);
+  return GORIO_UGPM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1309 @@
+// ugpm_kernels.hip -- gfx950 kernels of the UGPM GP pre-integration (gyro + radar ego-velocity), fp64 throughout.
+//
+// Reference lines replaced (paths relative to /root/reference/4DRadarSLAM/include/VelInt):
+//   lpm_init_kernel      5 LPM rotation integrations + 1 position integration, angle unwrapping, GP state / hyper-parameter
+//                        initialisation                                            preint.h:170-742, 1198-1399, 1444-1476
+//   gram_kernel          SE Gram matrix, (K + sz2 I)^-1 by Cholesky, K K^-1, K_int K^-1, posterior variances    preint.h:832-866
+//   cross_kernel         K_s K^-1 / K_s_int K^-1 tables of the two cost functions           cost_functions.h:183-190, 293-308
+//   rot_eval / vel_eval  residuals and analytic Jacobians of GpNorm + Rot / Vel cost functions         cost_functions.h:14-385
+//   corr_jac_kernel      stacked Jacobian of the state-correlation step                                   preint.h:887-937
+//   ata_kernel           J^T J (+ J^T r): LDS-tiled fp64 rank-k update, symmetric tiles only
+//   lm_step / lm_decide  Ceres-style trust-region Levenberg-Marquardt (normal equations, Cholesky in HBM/L2)  preint.h:943-967
+//   corr_factor_kernel   (J^T J + 1e-5 I) = L L^T, L^-1, diag(A^-1), correlation scaling                preint.h:1478-1492
+//   finish_kernel        alpha = K^-1 s, post-integration Jacobian tables                        preint.h:978-1060, 1401-1441
+//   infer_kernel         Se3Integrator::get(t) + the bias-prior inflation of VelPreintegration::get    preint.h:1069-1153, 1744-1757
+//
+// One workgroup (set) per window; windows are independent so a batch fills the chip without any inter-workgroup traffic.
+// The work is small dense fp64 algebra (S = 66 states, ~260 samples per sensor): matrices live in HBM but are L2 resident
+// (11 MB per window), tiles are staged through LDS in ata_kernel, and every reduction is a fixed-order tree, so results are
+// run-to-run reproducible.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "ugpm_device.h"
+
+namespace gorio {
+namespace ug {
+
+constexpr double kDt = 0.01;        // kNumDtJacobianDelta, math_utils.h:15
+constexpr double kBw = 0.0001;      // kNumGyrBiasJacobianDelta, math_utils.h:17
+constexpr double kExpTol = 1e-14;   // kExpNormTolerance, math_utils.h:11
+constexpr double kPi = 3.14159265358979323846;
+
+struct V3 {
+  double x, y, z;
+};
+struct M3 {
+  double m[9];
+};
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double vnorm(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ M3 eye3() { return M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+__device__ __forceinline__ M3 mmul(const M3& a, const M3& b) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = a.m[i * 3] * b.m[j] + a.m[i * 3 + 1] * b.m[3 + j] + a.m[i * 3 + 2] * b.m[6 + j];
+  return r;
+}
+__device__ __forceinline__ M3 mtr(const M3& a) { return M3{{a.m[0], a.m[3], a.m[6], a.m[1], a.m[4], a.m[7], a.m[2], a.m[5], a.m[8]}}; }
+__device__ __forceinline__ V3 mvec(const M3& a, V3 v) { return V3{a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z, a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z}; }
+__device__ __forceinline__ M3 skew(V3 v) { return M3{{0.0, -v.z, v.y, v.z, 0.0, -v.x, -v.y, v.x, 0.0}}; }
+__device__ __forceinline__ void store3(double* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ V3 load3(const double* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void storeM(double* p, const M3& a) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) p[i] = a.m[i];
+}
+__device__ __forceinline__ M3 loadM(const double* p) {
+  M3 a;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a.m[i] = p[i];
+  return a;
+}
+
+// expMap (math_utils.h:55-58): AngleAxis(|v|, v / |v|) -> c I + (1 - c) a a^T + s [a]x ; a zero vector gives I
+__device__ M3 expMap(V3 v) {
+  const double n2 = v.x * v.x + v.y * v.y + v.z * v.z;
+  const double ang = sqrt(n2);
+  V3 a = v;
+  if (n2 > 0.0) a = (1.0 / ang) * v;
+  const double s = sin(ang), c = cos(ang);
+  const V3 sa = s * a, ca = (1.0 - c) * a;
+  M3 R;
+  double t;
+  t = ca.x * a.y; R.m[1] = t - sa.z; R.m[3] = t + sa.z;
+  t = ca.x * a.z; R.m[2] = t + sa.y; R.m[6] = t - sa.y;
+  t = ca.y * a.z; R.m[5] = t - sa.x; R.m[7] = t + sa.x;
+  R.m[0] = ca.x * a.x + c; R.m[4] = ca.y * a.y + c; R.m[8] = ca.z * a.z + c;
+  return R;
+}
+
+// logMap (math_utils.h:48-51): rotation matrix -> quaternion -> angle * axis, angle in [0, pi]
+__device__ V3 logMap(const M3& R) {
+  double q[4];
+  double t = R.m[0] + R.m[4] + R.m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R.m[7] - R.m[5]) * t;
+    q[1] = (R.m[2] - R.m[6]) * t;
+    q[2] = (R.m[3] - R.m[1]) * t;
+  } else {
+    int i = 0;
+    if (R.m[4] > R.m[0]) i = 1;
+    if (R.m[8] > R.m[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(R.m[i * 4] - R.m[j * 4] - R.m[k * 4] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R.m[k * 3 + j] - R.m[j * 3 + k]) * t;
+    q[j] = (R.m[j * 3 + i] + R.m[i * 3 + j]) * t;
+    q[k] = (R.m[k * 3 + i] + R.m[i * 3 + k]) * t;
+  }
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+  if (n != 0.0) {
+    const double ang = 2.0 * atan2(n, fabs(q[3]));
+    if (q[3] < 0) n = -n;
+    return V3{ang * q[0] / n, ang * q[1] / n, ang * q[2] / n};
+  }
+  return V3{0, 0, 0};
+}
+
+// jacobianRighthandSO3 (math_utils.h:63-80) and its inverse (math_utils.h:83-99)
+__device__ M3 Jr(V3 v) {
+  M3 out = eye3();
+  const double n = vnorm(v);
+  if (n > kExpTol) {
+    const M3 S = skew(v), S2 = mmul(S, S);
+    const double a = (n - sin(n)) / (n * n * n), b = (1.0 - cos(n)) / (n * n);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.m[i] += a * S2.m[i] - b * S.m[i];
+  }
+  return out;
+}
+__device__ M3 JrInv(V3 v) {
+  M3 out = eye3();
+  const double n = vnorm(v);
+  if (n > kExpTol) {
+    const M3 S = skew(v), S2 = mmul(S, S);
+    const double a = (1.0 / (n * n)) - ((1 + cos(n)) / (2.0 * n * sin(n)));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.m[i] += 0.5 * S.m[i] + a * S2.m[i];
+  }
+  return out;
+}
+__device__ V3 addN2Pi(V3 r, int n) {  // math_utils.h:385-397
+  const double nr = vnorm(r);
+  if (nr != 0) return (2.0 * kPi * n + nr) * ((1.0 / nr) * r);
+  return r;
+}
+
+// SE kernel and its integral (math_utils.h:102-126); sqrt_inv_l2 = sqrt(1 / l2)
+__device__ __forceinline__ double se_k(double x1, double x2, double l2, double sf2) {
+  const double d = x1 - x2;
+  return exp((d * d) * (-0.5 / l2)) * sf2;
+}
+__device__ __forceinline__ double se_kint(double a, double b, double x2, double l2, double sf2) {
+  const double sq = sqrt(1.0 / l2);
+  const double alpha = sqrt(2.0) * sf2 * sqrt(kPi) / (2.0 * sq);
+  return alpha * (erf(sqrt(2.0) * (b - x2) * sq / 2.0) - erf(sqrt(2.0) * (-x2 + a) * sq / 2.0));
+}
+__device__ __forceinline__ double se_kint_dt(double a, double b, double x2, double l2, double sf2) {  // math_utils.h:130-141
+  return sf2 * exp(((b - x2) * (b - x2)) / (-2.0 * l2)) - sf2 * exp(((x2 - a) * (x2 - a)) / (-2.0 * l2));
+}
+__device__ __forceinline__ double kss_int(double a, double b, double l2, double sf2) {  // math_utils.h:378-382
+  return 2.0 * l2 * sf2 * exp(-((a - b) * (a - b)) / (2.0 * l2)) - 2.0 * l2 * sf2 + (sqrt(2.0) * sf2 * sqrt(kPi) * erf((sqrt(2.0) * (a - b) * sqrt(1.0 / l2)) / 2.0) * (a - b)) / sqrt(1.0 / l2);
+}
+
+// =============================================================================================== LPM initialisation
+
+// One LPM rotation integration (IterativeIntegrator::rotPreint, preint.h:321-391, 407-519) on ONE lane, streaming over the merged
+// time line instead of materialising it.  variant: 0 = data minus the bias prior; 1 = all sample times shifted by -0.01, no prior
+// (preint.h:1270-1285); 2..4 = gyro axis (variant - 2) + 1e-4, no prior, bare (preint.h:1338-1350).
+__device__ void lpm_rotation(const UgpmWin& w, int variant) {
+  const int S = w.S, G = w.G, V = w.V;
+  const double lpm_start = w.state_t[0];
+  const double tshift = variant == 1 ? kDt : 0.0;
+  // the time line is the union of 6 ascending lists (preint.h:214-237): 0 t_vect, 1 t_vect + 0.01, 2 {start_t}, 3 {lpm_start,
+  // lpm_start + 0.01}, 4 velocity stamps, 5 500 Hz filler stamps
+  int nl[6] = {S, S, 1, 2, V, 0};
+  double fake_first = 0.0, fake_q = 0.0;
+  auto val = [&](int l, int i) -> double {
+    switch (l) {
+      case 0: return w.state_t[i];
+      case 1: return w.state_t[i] + kDt;
+      case 2: return w.start_t;
+      case 3: return lpm_start + (i ? kDt : 0.0);
+      case 4: return w.vel_t[i] - tshift;
+      default: return fake_first + i * fake_q;
+    }
+  };
+  {  // filler decision, preint.h:228-237 with getSmallestGap() == LAST gap of the merged line (types.h:442-450)
+    double first = val(0, 0), top1 = -1e300, top2 = -1e300;
+    for (int l = 0; l < 5; ++l) {
+      if (nl[l] == 0) continue;
+      const double f = val(l, 0);
+      if (f < first) first = f;
+      for (int q = nl[l] - 1; q >= 0 && q >= nl[l] - 2; --q) {
+        const double c = val(l, q);
+        if (c > top1) {
+          top2 = top1;
+          top1 = c;
+        } else if (c > top2) {
+          top2 = c;
+        }
+      }
+    }
+    if ((top1 - top2) > (1.0 / 500.0)) {
+      const int nb = (int)floor((top1 - first) * 500.0);
+      if (nb > 0) {
+        nl[5] = nb;
+        fake_first = first;
+        fake_q = (top1 - first) / ((double)nb);
+      }
+    }
+  }
+  // gyro accessors for this variant
+  auto gt = [&](int i) -> double { return w.gyr_t[i] - tshift; };
+  auto gd = [&](int a, int i) -> double {
+    double d = w.gyr[a * G + i];
+    if (variant == 0) d -= w.gyr_bias[a];
+    if (variant - 2 == a) d += kBw;
+    return d;
+  };
+  // linearInterpolation state per axis (math_utils.h:487-532)
+  int ptr[3] = {0, 0, 0};
+  double al[3], be[3];
+  for (int a = 0; a < 3; ++a) {
+    al[a] = (gd(a, 1) - gd(a, 0)) / (gt(1) - gt(0));
+    be[a] = gd(a, 0) - (al[a] * gt(0));
+  }
+  const double gt0 = gt(0);
+  auto interp = [&](double t, double* out) {
+    for (int a = 0; a < 3; ++a) {
+      if (t > gt0) {
+        while (ptr[a] != (G - 2)) {
+          if ((t <= gt(ptr[a] + 1)) && (t > gt(ptr[a]))) break;
+          ptr[a]++;
+          al[a] = (gd(a, ptr[a] + 1) - gd(a, ptr[a])) / (gt(ptr[a] + 1) - gt(ptr[a]));
+          be[a] = gd(a, ptr[a]) - (al[a] * gt(ptr[a]));
+        }
+      }
+      out[a] = al[a] * t + be[a];
+    }
+  };
+  // streaming merge; ties are emitted in the list order 3, 0, 1, 2, 4, 5 so that nothing captured precedes the LPM start stamp
+  const int order[6] = {3, 0, 1, 2, 4, 5};
+  int p[6] = {0, 0, 0, 0, 0, 0};
+  int total = 0;
+  for (int l = 0; l < 6; ++l) total += nl[l];
+  M3 R = eye3();
+  double t_prev = 0.0, w_prev[3] = {0, 0, 0};
+  double* Rq = w.Rq + (size_t)variant * 2 * S * 9;
+  for (int step = 0; step < total; ++step) {
+    int bl = -1;
+    double bt = 0.0;
+    for (int o = 0; o < 6; ++o) {
+      const int l = order[o];
+      if (p[l] < nl[l]) {
+        const double c = val(l, p[l]);
+        if (bl < 0 || c < bt) {
+          bl = l;
+          bt = c;
+        }
+      }
+    }
+    const int idx = p[bl]++;
+    if (step > 0) {  // rotIterativeIntegration, preint.h:421-453 / 496-506
+      const double dt = bt - t_prev;
+      R = mmul(R, expMap(v3(w_prev[0] * dt, w_prev[1] * dt, w_prev[2] * dt)));
+    }
+    if (bl == 3 && idx == 0) R = eye3();  // start_index_: re-reference to the LPM start (preint.h:477-485, 509-517)
+    if (bl == 0) storeM(Rq + (size_t)idx * 9, R);
+    else if (bl == 1) storeM(Rq + (size_t)(S + idx) * 9, R);
+    else if (bl == 2) storeM(w.Rstart + variant * 9, R);
+    else if (bl == 4 && variant == 0) {  // reprojectVelData, math_utils.h:415-426
+      const V3 vr = mvec(R, v3(w.vel[idx] - w.vel_bias[0], w.vel[V + idx] - w.vel_bias[1], w.vel[2 * V + idx] - w.vel_bias[2]));
+      w.velr[idx] = vr.x;
+      w.velr[V + idx] = vr.y;
+      w.velr[2 * V + idx] = vr.z;
+    }
+    interp(bt, w_prev);
+    t_prev = bt;
+  }
+}
+
+// Trapezoid position integration of the rotated velocity (posePreintLPM main loop, preint.h:552-665, values only) for one axis.
+__device__ void lpm_position(const UgpmWin& w, int axis) {
+  const int S = w.S, V = w.V;
+  const double start = w.state_t[0];
+  const double* vt = w.vel_t;
+  const double* vd = w.velr + (size_t)axis * V;
+  int data_ptr = 0;
+  while (vt[data_ptr + 1] < start) {
+    data_ptr++;
+    if (data_ptr == V - 1) {
+      *w.status = -3;
+      return;
+    }
+  }
+  int ptr = data_ptr;
+  double alpha = (vd[ptr + 1] - vd[ptr]) / (vt[ptr + 1] - vt[ptr]);
+  double beta = vd[ptr] - alpha * vt[ptr];
+  double t_0 = start, t_1 = vt[ptr + 1];
+  double d_0 = alpha * vt[ptr] + beta, d_1 = vd[ptr + 1];
+  double backup = 0.0;
+  int p0 = 0, p1 = 0, p2 = 0;  // query lists: t_vect, t_vect + 0.01, {start_t}
+  for (int step = 0; step < 2 * S + 1; ++step) {
+    int bl = -1;
+    double t = 0.0;
+    if (p0 < S) { bl = 0; t = w.state_t[p0]; }
+    if (p1 < S && (bl < 0 || w.state_t[p1] + kDt < t)) { bl = 1; t = w.state_t[p1] + kDt; }
+    if (p2 < 1 && (bl < 0 || w.start_t < t)) { bl = 2; t = w.start_t; }
+    int idx = 0;
+    if (bl == 0) idx = p0++;
+    else if (bl == 1) idx = p1++;
+    else p2++;
+    if (t > vt[0]) {
+      while (true) {
+        if ((t >= vt[ptr]) && (t <= vt[ptr + 1])) break;
+        if (ptr < (V - 2)) {
+          backup = backup + ((t_1 - t_0) * (d_0 + d_1) / 2.0);
+          ptr++;
+          t_0 = vt[ptr];
+          t_1 = vt[ptr + 1];
+          d_0 = vd[ptr];
+          d_1 = vd[ptr + 1];
+          alpha = (d_1 - d_0) / (t_1 - t_0);
+          beta = d_0 - alpha * t_0;
+        } else {
+          break;
+        }
+      }
+    }
+    const double temp_d_1 = alpha * t + beta;
+    const double temp_d_p = backup + ((t - t_0) * (d_0 + temp_d_1) / 2.0);
+    if (bl < 2) w.dp[((size_t)bl * S + idx) * 3 + axis] = temp_d_p;
+  }
+}
+
+// 2 pi unwrapping of the rotation vectors (preint.h:1214-1263 and the three copies in 1288-1395)
+__device__ void unwrap_variant(const UgpmWin& w, int variant) {
+  const int S = w.S;
+  const M3 sRt = mtr(loadM(w.Rstart + variant * 9));
+  const double* Rq = w.Rq + (size_t)variant * 2 * S * 9;
+  double* r0 = w.r0 + (size_t)variant * S * 3;
+  double* r1 = w.r1 + (size_t)variant * S * 3;
+  for (int pass = 0; pass < 2; ++pass) {
+    int rev[2] = {0, 0};
+    V3 prev[2] = {v3(0, 0, 0), v3(0, 0, 0)};
+    const int from = pass == 0 ? w.overlap : w.overlap - 1, to = pass == 0 ? S : -1, stp = pass == 0 ? 1 : -1;
+    for (int i = from; i != to; i += stp) {
+      for (int j = 0; j < 2; ++j) {
+        const V3 tr = logMap(mmul(sRt, loadM(Rq + ((size_t)j * S + i) * 9)));
+        int id = 0;
+        double best = 1.7976931348623157e308;
+        V3 bc = tr;
+        for (int q = 0; q < 3; ++q) {
+          const V3 c = addN2Pi(tr, rev[j] + q - 1);
+          const double d = vnorm(prev[j] - c);
+          if (d < best) {
+            best = d;
+            id = q;
+            bc = c;
+          }
+        }
+        prev[j] = bc;
+        rev[j] += (id - 1);
+      }
+      store3(r0 + (size_t)i * 3, prev[0]);
+      store3(r1 + (size_t)i * 3, prev[1]);
+    }
+  }
+}
+
+// grid: (windows), block 320 = 5 waves; wave v's first lane integrates LPM variant v.
+__global__ __launch_bounds__(320) void lpm_init_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0) return;
+  const int v = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int S = w.S;
+  if (lane == 0) lpm_rotation(w, v);
+  __syncthreads();
+  if (v == 0 && lane < 3) lpm_position(w, lane);
+  if (lane == 0) unwrap_variant(w, v);
+  __syncthreads();
+  if (*w.status != 0) return;
+  const M3 sRt0 = mtr(loadM(w.Rstart));
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {  // preint.h:1231-1236, 1304-1307, 1369-1372
+    const V3 a0 = load3(w.r0 + (size_t)i * 3), a1 = load3(w.r1 + (size_t)i * 3);
+    const V3 d = (1.0 / kDt) * (a1 - a0);
+    w.s_dr[i] = d.x; w.s_dr[S + i] = d.y; w.s_dr[2 * S + i] = d.z;
+    const V3 vel = mvec(sRt0, (1.0 / kDt) * (load3(w.dp + ((size_t)S + i) * 3) - load3(w.dp + (size_t)i * 3)));
+    w.s_vel[i] = vel.x; w.s_vel[S + i] = vel.y; w.s_vel[2 * S + i] = vel.z;
+    store3(w.d_r_dt_local + (size_t)i * 3, mvec(Jr(a0), d));
+    {
+      const V3 b0 = load3(w.r0 + ((size_t)S + i) * 3), b1 = load3(w.r1 + ((size_t)S + i) * 3);
+      const M3 J = Jr(b0);
+      store3(w.d_r_dt_local_shift + (size_t)i * 3, mvec(J, (1.0 / kDt) * (b1 - b0)));
+      store3(w.delta_r_time + (size_t)i * 3, mvec(J, b0 - a0));
+    }
+    for (int ax = 0; ax < 3; ++ax) {
+      const V3 b0 = load3(w.r0 + ((size_t)(2 + ax) * S + i) * 3), b1 = load3(w.r1 + ((size_t)(2 + ax) * S + i) * 3);
+      const M3 J = Jr(b0);
+      store3(w.d_r_bw_local_shift + ((size_t)ax * S + i) * 3, mvec(J, (1.0 / kDt) * (b1 - b0)));
+      store3(w.delta_r_bw + ((size_t)ax * S + i) * 3, mvec(J, b0 - a0));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {  // initialiseHyperParam, preint.h:1444-1476
+    const int c = threadIdx.x;
+    double* s = (c < 3 ? w.s_dr + (size_t)c * S : w.s_vel + (size_t)(c - 3) * S);
+    double m = 0.0;
+    for (int i = 0; i < S; ++i) m += s[i];
+    m /= (double)S;
+    double var = 0.0;
+    for (int i = 0; i < S; ++i) var += (s[i] - m) * (s[i] - m);
+    var /= (double)S;
+    const double noise = c < 3 ? w.gyr_var : w.vel_var;
+    w.hyper[c * 4 + 0] = (3.0 / w.state_freq) * (3.0 / w.state_freq);
+    w.hyper[c * 4 + 1] = fmax(var, noise);
+    w.hyper[c * 4 + 2] = noise;
+    w.hyper[c * 4 + 3] = m;
+    for (int i = 0; i < S; ++i) s[i] -= m;
+  }
+}
+
+// =============================================================================================== block-wide dense helpers
+
+// in-place lower Cholesky of the n x n matrix A (row-major, leading dimension lda) by one workgroup; returns false on a
+// non-positive pivot.  Right-looking, column at a time; the upper triangle is not referenced.
+__device__ bool block_cholesky(double* __restrict__ A, int n, int lda, int* __restrict__ sflag) {
+  if (threadIdx.x == 0) *sflag = 0;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    const double ajj = A[(size_t)j * lda + j];
+    if (!(ajj > 0.0)) {
+      if (threadIdx.x == 0) *sflag = 1;
+      __syncthreads();
+      return false;
+    }
+    const double d = sqrt(ajj);
+    __syncthreads();
+    for (int i = j + threadIdx.x; i < n; i += blockDim.x) A[(size_t)i * lda + j] = (i == j) ? d : A[(size_t)i * lda + j] / d;
+    __syncthreads();
+    // trailing update of the lower triangle: A[i][k] -= L[i][j] L[k][j], j < k <= i
+    const int m = n - j - 1;
+    const long cnt = (long)m * (m + 1) / 2;
+    for (long q = threadIdx.x; q < cnt; q += blockDim.x) {
+      // unrank q -> (r, c) with 0 <= c <= r < m
+      int r = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+      while ((long)r * (r + 1) / 2 > q) --r;
+      while ((long)(r + 1) * (r + 2) / 2 <= q) ++r;
+      const int c = (int)(q - (long)r * (r + 1) / 2);
+      const int i = j + 1 + r, k = j + 1 + c;
+      A[(size_t)i * lda + k] -= A[(size_t)i * lda + j] * A[(size_t)k * lda + j];
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
+// Linv = L^-1 (lower triangular), one column per thread (forward substitution against e_col)
+__device__ void block_tri_inverse(const double* __restrict__ L, double* __restrict__ Li, int n, int lda) {
+  for (int col = threadIdx.x; col < n; col += blockDim.x) {
+    for (int i = 0; i < col; ++i) Li[(size_t)i * lda + col] = 0.0;
+    Li[(size_t)col * lda + col] = 1.0 / L[(size_t)col * lda + col];
+    for (int i = col + 1; i < n; ++i) {
+      double s = 0.0;
+      for (int k = col; k < i; ++k) s -= L[(size_t)i * lda + k] * Li[(size_t)k * lda + col];
+      Li[(size_t)i * lda + col] = s / L[(size_t)i * lda + i];
+    }
+  }
+  __syncthreads();
+}
+
+// x = (L L^T)^-1 b with the column-oriented substitution (all threads update the remaining right-hand side)
+__device__ void block_chol_solve(const double* __restrict__ L, int n, int lda, double* __restrict__ x /* in: b, out: x */) {
+  for (int j = 0; j < n; ++j) {
+    __syncthreads();
+    const double xj = x[j] / L[(size_t)j * lda + j];
+    __syncthreads();
+    if (threadIdx.x == 0) x[j] = xj;
+    for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) x[i] -= L[(size_t)i * lda + j] * xj;
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    __syncthreads();
+    const double xj = x[j] / L[(size_t)j * lda + j];
+    __syncthreads();
+    if (threadIdx.x == 0) x[j] = xj;
+    for (int i = threadIdx.x; i < j; i += blockDim.x) x[i] -= L[(size_t)j * lda + i] * xj;
+  }
+  __syncthreads();
+}
+
+__device__ double block_sum(double v, double* sred) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sred[q];
+  return t;
+}
+__device__ double block_max(double v, double* sred) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = sred[0];
+  for (int q = 1; q < (int)(blockDim.x >> 6); ++q) t = fmax(t, sred[q]);
+  return t;
+}
+
+// =============================================================================================== Gram stage
+
+// grid: (6 channels, windows), block 256.  preint.h:832-866 for one channel.
+__global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.y];
+  if (*w.status != 0) return;
+  const int c = blockIdx.x, S = w.S;
+  const double l2 = w.hyper[c * 4 + 0], sf2 = w.hyper[c * 4 + 1], sz2 = w.hyper[c * 4 + 2];
+  double* A = w.Kinv + (size_t)c * S * S;    // K + sz2 I -> L -> finally K^-1
+  double* B = w.KKinv + (size_t)c * S * S;   // L^-1 scratch -> finally K K^-1
+  const double* st = w.state_t;
+  __shared__ int sflag;
+  for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
+    const int i = q / S, j = q % S;
+    A[q] = se_k(st[i], st[j], l2, sf2) + (i == j ? sz2 : 0.0);
+  }
+  __syncthreads();
+  if (!block_cholesky(A, S, S, &sflag)) {
+    if (threadIdx.x == 0) *w.status = -6;
+    return;
+  }
+  block_tri_inverse(A, B, S, S);
+  // K^-1 = L^-T L^-1 (symmetric): K^-1[i][j] = sum_{k >= max(i,j)} Li[k][i] Li[k][j]
+  for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
+    const int i = q / S, j = q % S;
+    double s = 0.0;
+    for (int k = (i > j ? i : j); k < S; ++k) s += B[(size_t)k * S + i] * B[(size_t)k * S + j];
+    A[q] = s;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < S * S; q += blockDim.x) {  // K K^-1, preint.h:838
+    const int i = q / S, j = q % S;
+    double s = 0.0;
+    for (int k = 0; k < S; ++k) s += se_k(st[i], st[k], l2, sf2) * A[(size_t)k * S + j];
+    B[q] = s;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < S; j += blockDim.x) {  // preint.h:846-864
+    double s = 0.0;
+    for (int k = 0; k < S; ++k) s += B[(size_t)j * S + k] * se_k(st[k], st[j], l2, sf2);
+    double v = -s + sf2 + sz2;
+    if (v <= 0) v = sz2;
+    w.var[c * S + j] = v;
+    w.sstd[c * S + j] = sqrt(v);
+    double wt = sqrt(1.0 / (1000.0 * v));  // cost_functions.h:31 with the 1000 x variance of preint.h:853, 864
+    if (isnan(wt)) wt = 1.0;
+    w.wgp[c * S + j] = wt;
+  }
+  if (c < 3) {  // K_int K^-1, preint.h:842-844
+    double* C = w.KintKinv + (size_t)c * S * S;
+    for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
+      const int i = q / S, j = q % S;
+      double s = 0.0;
+      for (int k = 0; k < S; ++k) s += se_kint(w.start_t, st[i], st[k], l2, sf2) * A[(size_t)k * S + j];
+      C[q] = s;
+    }
+  }
+}
+
+// grid: (12 tables, windows, row tiles of 8), block 256.  Tables 0-2 K_s K^-1 (gyro stamps), 3-5 K_s_int K^-1 (gyro stamps),
+// 6-8 K_s_int K^-1 (velocity stamps, rotation channels), 9-11 K_s K^-1 (velocity stamps, velocity channels).
+__global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.y];
+  if (*w.status != 0) return;
+  const int tab = blockIdx.x, S = w.S;
+  const int c = tab % 3, kind = tab / 3;
+  const int ch = kind == 3 ? 3 + c : c;
+  const int N = kind < 2 ? w.G : w.V;
+  const double* tt = kind < 2 ? w.gyr_t : w.vel_t;
+  double* out = (kind == 0 ? w.KsKinv : kind == 1 ? w.KsIntKinv : kind == 2 ? w.KgyrIntKinv : w.KvelKinv) + (size_t)c * N * S;
+  const double* Ki = w.Kinv + (size_t)ch * S * S;
+  const double l2 = w.hyper[ch * 4 + 0], sf2 = w.hyper[ch * 4 + 1];
+  const bool integral = (kind == 1 || kind == 2);
+  __shared__ double ks[8][160];
+  const int row0 = blockIdx.z * 8;
+  if (row0 >= N) return;
+  for (int q = threadIdx.x; q < 8 * S; q += blockDim.x) {
+    const int r = q / S, k = q % S;
+    const int n = row0 + r;
+    if (n < N) ks[r][k] = integral ? se_kint(w.start_t, tt[n], w.state_t[k], l2, sf2) : se_k(tt[n], w.state_t[k], l2, sf2);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 8 * S; q += blockDim.x) {
+    const int r = q / S, j = q % S;
+    const int n = row0 + r;
+    if (n >= N) continue;
+    double s = 0.0;
+    for (int k = 0; k < S; ++k) s += ks[r][k] * Ki[(size_t)k * S + j];
+    out[(size_t)n * S + j] = s;
+  }
+}
+
+// =============================================================================================== cost functions
+
+// d[J_r(r) dr] / d[r, dr] (cost_functions.h:73-145; the reference's symbolic dump is this derivative written out):
+//   d/dr_k = -A' (r_k/n) (r x dr) - A (e_k x dr) + B' (r_k/n) (r x (r x dr)) + B (e_k x (r x dr) + r x (e_k x dr)),  d/d(dr) = J_r(r)
+__device__ void jacobian_res(V3 r, V3 dr, double D[3][6]) {
+  const double n2 = r.x * r.x + r.y * r.y + r.z * r.z;
+  const double n = sqrt(n2);
+  if (n > kExpTol) {
+    const double s = sin(n), c = cos(n);
+    const double A = (1.0 - c) / n2, B = (n - s) / (n2 * n);
+    const double dA = (n * s - 2.0 * (1.0 - c)) / (n2 * n);
+    const double dB = ((1.0 - c) * n - 3.0 * (n - s)) / (n2 * n2);
+    const V3 rxd = cross(r, dr), rxrxd = cross(r, rxd);
+    const double rk[3] = {r.x, r.y, r.z};
+    for (int k = 0; k < 3; ++k) {
+      const V3 e = v3(k == 0, k == 1, k == 2);
+      const double dn = rk[k] / n;
+      const V3 exd = cross(e, dr);
+      const V3 t = (-dA * dn) * rxd + (-A) * exd + (dB * dn) * rxrxd + B * (cross(e, rxd) + cross(r, exd));
+      D[0][k] = t.x; D[1][k] = t.y; D[2][k] = t.z;
+    }
+    const M3 J = Jr(r);
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) D[i][3 + k] = J.m[i * 3 + k];
+  } else {
+    const M3 S = skew(dr);
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) {
+        D[i][k] = 0.5 * S.m[i * 3 + k];
+        D[i][3 + k] = (i == k) ? 1.0 : 0.0;
+      }
+  }
+}
+
+__device__ __forceinline__ double row_dot(const double* __restrict__ row, const double* __restrict__ s, int S) {
+  double t = 0.0;
+  for (int j = 0; j < S; ++j) t += row[j] * s[j];
+  return t;
+}
+
+// GpNorm residual rows [0, S) of channel block `blk` (cost_functions.h:47-57) and, once, its constant Jacobian block
+// J(r, c) = (KKinv - I)(c, r) w[r]  (cost_functions.h:36-42 as seen by the solver through the column-major map at :63-64)
+__device__ void gpnorm_rows(const UgpmWin& w, int ch, const double* __restrict__ s, double* __restrict__ res, double* __restrict__ J, int ldj, int col0, bool writeJ) {
+  const int S = w.S;
+  const double* KK = w.KKinv + (size_t)ch * S * S;
+  const double* wt = w.wgp + (size_t)ch * S;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) res[i] = (row_dot(KK + (size_t)i * S, s, S) - s[i]) * wt[i];
+  if (writeJ)
+    for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
+      const int i = q / S, j = q % S;
+      J[(size_t)i * ldj + col0 + j] = (KK[(size_t)j * S + i] - (i == j ? 1.0 : 0.0)) * wt[i];
+    }
+}
+
+// Problem #1 (preint.h:872-952): unknowns x = [s_dr0 | s_dr1 | s_dr2] (3S); rows = 3 GpNorm blocks (3S) then RotCost (3G).
+// grid: (windows), block 256.  mode: 0 residual at x_new -> res_new; 1 residual + Jacobian at x -> res, Jrot; 2 as 1 and also
+// (re)writes the constant GpNorm blocks and zeroes the rest (first evaluation).
+__global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict__ wins, int mode) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0 || w.lmi[1]) return;
+  if (mode == 1 && !w.lmi[3]) return;  // Jacobian only needed after an accepted step
+  const int S = w.S, G = w.G, n = 3 * S;
+  const double* x = mode == 0 ? w.lmv + 6 * (size_t)n : w.lmv + 5 * (size_t)n;
+  double* res = mode == 0 ? w.res_new : w.res;
+  double* J = w.Jrot;
+  if (mode == 2)
+    for (size_t q = threadIdx.x; q < (size_t)(3 * S + 3 * G) * n; q += blockDim.x) J[q] = 0.0;
+  __syncthreads();
+  for (int c = 0; c < 3; ++c) gpnorm_rows(w, c, x + (size_t)c * S, res + (size_t)c * S, J + (size_t)c * S * n, n, c * S, mode == 2);
+  for (int i = threadIdx.x; i < G; i += blockDim.x) {  // cost_functions.h:201-253
+    double rot[3], drv[3];
+    for (int c = 0; c < 3; ++c) {
+      drv[c] = row_dot(w.KsKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
+      rot[c] = row_dot(w.KsIntKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
+    }
+    const double dtm = w.gyr_t[i] - w.start_t;
+    const V3 rv = v3(rot[0] + dtm * w.hyper[3], rot[1] + dtm * w.hyper[7], rot[2] + dtm * w.hyper[11]);
+    const V3 dv = v3(drv[0] + w.hyper[3], drv[1] + w.hyper[7], drv[2] + w.hyper[11]);
+    const V3 t = mvec(Jr(rv), dv);
+    double* r = res + 3 * S + 3 * i;
+    r[0] = t.x - (w.gyr[i] - w.gyr_bias[0]);  // un-weighted on purpose (cost_functions.h:250)
+    r[1] = t.y - (w.gyr[G + i] - w.gyr_bias[1]);
+    r[2] = t.z - (w.gyr[2 * G + i] - w.gyr_bias[2]);
+    if (mode != 0) {
+      double D[3][6];
+      jacobian_res(rv, dv, D);
+      double* st = w.sample_tmp + (size_t)i * 24;
+      for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < 6; ++k) st[a * 6 + k] = D[a][k];
+    }
+  }
+  if (mode == 0) return;
+  __syncthreads();
+  for (size_t q = threadIdx.x; q < (size_t)G * 3 * n; q += blockDim.x) {  // cost_functions.h:229-246
+    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / n) % 3), i = (int)(q / ((size_t)3 * n));
+    const double* st = w.sample_tmp + (size_t)i * 24;
+    J[((size_t)(3 * S + 3 * i + a)) * n + c * S + j] = st[a * 6 + c] * w.KsIntKinv[((size_t)c * G + i) * S + j] + st[a * 6 + c + 3] * w.KsKinv[((size_t)c * G + i) * S + j];
+  }
+}
+
+// rotation vector / R^T at a velocity stamp from the (now constant) rotation states (cost_functions.h:333-353)
+__device__ __forceinline__ V3 vel_rot_vec(const UgpmWin& w, int i) {
+  const int S = w.S, V = w.V;
+  double rot[3];
+  for (int c = 0; c < 3; ++c) rot[c] = row_dot(w.KgyrIntKinv + ((size_t)c * V + i) * S, w.s_dr + (size_t)c * S, S);
+  const double dtm = w.vel_t[i] - w.start_t;
+  return v3(rot[0] + dtm * w.hyper[3], rot[1] + dtm * w.hyper[7], rot[2] + dtm * w.hyper[11]);
+}
+
+// Problem #2 (preint.h:954-967): rotation states constant; x = [s_vel0 | s_vel1 | s_vel2]; rows = VelCost (3V) then 3 GpNorm (3S).
+__global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict__ wins, int mode) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0 || w.lmi[1]) return;
+  if (mode == 1 && !w.lmi[3]) return;
+  const int S = w.S, V = w.V, n = 3 * S;
+  const double* x = mode == 0 ? w.lmv + 6 * (size_t)n : w.lmv + 5 * (size_t)n;
+  double* res = mode == 0 ? w.res_new : w.res;
+  double* J = w.Jvel;
+  if (mode == 2)
+    for (size_t q = threadIdx.x; q < (size_t)(3 * S + 3 * V) * n; q += blockDim.x) J[q] = 0.0;
+  __syncthreads();
+  for (int c = 0; c < 3; ++c) gpnorm_rows(w, 3 + c, x + (size_t)c * S, res + 3 * V + (size_t)c * S, J + ((size_t)3 * V + (size_t)c * S) * n, n, c * S, mode == 2);
+  const double wgt = sqrt(1.0 / w.vel_var);
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {  // cost_functions.h:323-381
+    const V3 rv = vel_rot_vec(w, i);
+    const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
+    double vel[3];
+    for (int c = 0; c < 3; ++c) vel[c] = row_dot(w.KvelKinv + ((size_t)c * V + i) * S, x + (size_t)c * S, S);
+    const V3 vv = v3(vel[0] + w.hyper[15], vel[1] + w.hyper[19], vel[2] + w.hyper[23]);
+    const V3 t = mvec(RT, vv);
+    double* r = res + 3 * i;
+    r[0] = (t.x - (w.vel[i] - w.vel_bias[0])) * wgt;
+    r[1] = (t.y - (w.vel[V + i] - w.vel_bias[1])) * wgt;
+    r[2] = (t.z - (w.vel[2 * V + i] - w.vel_bias[2])) * wgt;
+    if (mode != 0) storeM(w.sample_tmp + (size_t)i * 24, RT);
+  }
+  if (mode == 0) return;
+  __syncthreads();
+  for (size_t q = threadIdx.x; q < (size_t)V * 3 * n; q += blockDim.x) {  // cost_functions.h:372-376
+    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / n) % 3), i = (int)(q / ((size_t)3 * n));
+    J[((size_t)(3 * i + a)) * n + c * S + j] = wgt * w.sample_tmp[(size_t)i * 24 + a * 3 + c] * w.KvelKinv[((size_t)c * V + i) * S + j];
+  }
+}
+
+// Stacked Jacobian of the correlation step at the LPM-initialised state (preint.h:887-937): rows 3G (RotCost) + 3V (VelCost),
+// columns 6S = [rot channels | velocity channels].  grid: (windows), block 256.
+__global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0 || !w.correlate) return;
+  const int S = w.S, G = w.G, V = w.V, n = 6 * S;
+  double* J = w.Jc;
+  for (size_t q = threadIdx.x; q < (size_t)(3 * G + 3 * V) * n; q += blockDim.x) J[q] = 0.0;
+  const double wgt = sqrt(1.0 / w.vel_var);
+  for (int i = threadIdx.x; i < G; i += blockDim.x) {
+    double rot[3], drv[3];
+    for (int c = 0; c < 3; ++c) {
+      drv[c] = row_dot(w.KsKinv + ((size_t)c * G + i) * S, w.s_dr + (size_t)c * S, S);
+      rot[c] = row_dot(w.KsIntKinv + ((size_t)c * G + i) * S, w.s_dr + (size_t)c * S, S);
+    }
+    const double dtm = w.gyr_t[i] - w.start_t;
+    double D[3][6];
+    jacobian_res(v3(rot[0] + dtm * w.hyper[3], rot[1] + dtm * w.hyper[7], rot[2] + dtm * w.hyper[11]), v3(drv[0] + w.hyper[3], drv[1] + w.hyper[7], drv[2] + w.hyper[11]), D);
+    double* st = w.sample_tmp + (size_t)i * 24;
+    for (int a = 0; a < 3; ++a)
+      for (int k = 0; k < 6; ++k) st[a * 6 + k] = D[a][k];
+  }
+  __syncthreads();
+  for (size_t q = threadIdx.x; q < (size_t)G * 9 * S; q += blockDim.x) {
+    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / (3 * S)) % 3), i = (int)(q / ((size_t)9 * S));
+    const double* st = w.sample_tmp + (size_t)i * 24;
+    J[((size_t)(3 * i + a)) * n + c * S + j] = st[a * 6 + c] * w.KsIntKinv[((size_t)c * G + i) * S + j] + st[a * 6 + c + 3] * w.KsKinv[((size_t)c * G + i) * S + j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V; i += blockDim.x) {  // cost_functions.h:350-377 with all six blocks
+    const V3 rv = vel_rot_vec(w, i);
+    const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
+    double vel[3];
+    for (int c = 0; c < 3; ++c) vel[c] = row_dot(w.KvelKinv + ((size_t)c * V + i) * S, w.s_vel + (size_t)c * S, S);
+    const V3 t = mvec(RT, v3(vel[0] + w.hyper[15], vel[1] + w.hyper[19], vel[2] + w.hyper[23]));
+    const M3 dres = mmul(skew(t), Jr(rv));
+    double* st = w.sample_tmp + (size_t)i * 24;
+    storeM(st, dres);
+    storeM(st + 9, RT);
+  }
+  __syncthreads();
+  for (size_t q = threadIdx.x; q < (size_t)V * 9 * S; q += blockDim.x) {
+    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / (3 * S)) % 3), i = (int)(q / ((size_t)9 * S));
+    const double* st = w.sample_tmp + (size_t)i * 24;
+    const size_t row = (size_t)(3 * G + 3 * i + a) * n;
+    J[row + c * S + j] = wgt * st[a * 3 + c] * w.KgyrIntKinv[((size_t)c * V + i) * S + j];
+    J[row + (3 + c) * S + j] = wgt * st[9 + a * 3 + c] * w.KvelKinv[((size_t)c * V + i) * S + j];
+  }
+}
+
+// =============================================================================================== J^T J
+
+// C = A^T A for A (m x n, row-major): 64 x 64 output tiles, 16-deep k panels staged through LDS, 256 threads x (4 x 4) fp64
+// accumulators; only tiles with tj >= ti are computed and mirrored.  Optionally g = A^T r (tile row 0 does it).
+// grid: (tiles, tiles, windows).  which: 0 rot problem, 1 vel problem, 2 correlation.
+__global__ __launch_bounds__(256) void ata_kernel(const UgpmWin* __restrict__ wins, int which) {
+  const UgpmWin& w = wins[blockIdx.z];
+  if (*w.status != 0) return;
+  int m, n;
+  const double* A;
+  double* C;
+  const double* r = nullptr;
+  double* g = nullptr;
+  if (which == 2) {
+    if (!w.correlate) return;
+    m = 3 * w.G + 3 * w.V; n = 6 * w.S; A = w.Jc; C = w.Ac;
+  } else {
+    if (w.lmi[1] || !w.lmi[3]) return;
+    n = 3 * w.S;
+    m = which == 0 ? 3 * w.S + 3 * w.G : 3 * w.V + 3 * w.S;
+    A = which == 0 ? w.Jrot : w.Jvel;
+    C = w.JtJ; r = w.res; g = w.lmv;
+  }
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (tj < ti || ti * 64 >= n || tj * 64 >= n) return;
+  __shared__ double sa[16][64], sb[16][64];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  double gacc[4] = {0, 0, 0, 0};
+  const bool do_g = (g != nullptr) && ti == 0 && ty == 0;  // g for the columns of tile column tj, by the 16 threads of ty == 0
+  for (int k0 = 0; k0 < m; k0 += 16) {
+    for (int q = threadIdx.x; q < 16 * 64; q += 256) {
+      const int kk = q >> 6, cc = q & 63;
+      const int k = k0 + kk;
+      const int ci = ti * 64 + cc, cj = tj * 64 + cc;
+      sa[kk][cc] = (k < m && ci < n) ? A[(size_t)k * n + ci] : 0.0;
+      sb[kk][cc] = (k < m && cj < n) ? A[(size_t)k * n + cj] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = sa[kk][ty * 4 + a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = sb[kk][tx * 4 + b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+      if (do_g) {
+        const int k = k0 + kk;
+        const double rk = k < m ? r[k] : 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) gacc[b] += bv[b] * rk;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ti * 64 + ty * 4 + a, j = tj * 64 + tx * 4 + b;
+      if (i < n && j < n) {
+        C[(size_t)i * n + j] = acc[a][b];
+        C[(size_t)j * n + i] = acc[a][b];
+      }
+    }
+  if (do_g)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = tj * 64 + tx * 4 + b;
+      if (j < n) g[j] = gacc[b];
+    }
+}
+
+// =============================================================================================== Levenberg-Marquardt (Ceres 2.1 defaults + preint.h:943-948)
+// lmv layout (vectors of n = 3S): 0 g = J^T r (unscaled), 1 scale, 2 diag, 3 step (scaled), 4 delta (unscaled), 5 x, 6 x_new, 7 rhs
+// lmc: 0 cost, 1 cost_new, 2 radius, 3 decrease_factor, 4 x_norm, 5 model_cost_change, 6 step_norm, 7 initial cost
+// lmi: 0 iter, 1 done, 2 reuse_diag, 3 need_J, 4 step_valid, 5 termination, 6 successful, 7 problem, 8 first
+
+// start a problem: load x, reset the control block.  grid: (windows), block 256.
+__global__ __launch_bounds__(256) void lm_begin_kernel(const UgpmWin* __restrict__ wins, int problem) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0) return;
+  const int n = 3 * w.S;
+  const double* src = problem == 0 ? w.s_dr : w.s_vel;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) w.lmv[5 * (size_t)n + j] = src[j];
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 16; ++q) w.lmi[q] = 0;
+    w.lmi[3] = 1;  // need_J
+    w.lmi[7] = problem;
+    w.lmi[8] = 1;  // first evaluation: scaling and the gradient check of iteration zero are pending
+    w.lmc[2] = 1e4;
+    w.lmc[3] = 2.0;
+  }
+}
+
+// One trust-region step: (on fresh J^T J) cost / gradient test / Jacobi scaling, then solve (D J^T J D + diag / radius) y = D g,
+// step = -y, delta = D step, model cost change, candidate x_new.  grid: (windows), block 256.
+__global__ __launch_bounds__(256) void lm_step_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0 || w.lmi[1]) return;
+  const int n = 3 * w.S;
+  const int problem = w.lmi[7];
+  const int m = problem == 0 ? 3 * w.S + 3 * w.G : 3 * w.V + 3 * w.S;
+  double* g = w.lmv;
+  double* scale = w.lmv + (size_t)n;
+  double* diag = w.lmv + 2 * (size_t)n;
+  double* step = w.lmv + 3 * (size_t)n;
+  double* delta = w.lmv + 4 * (size_t)n;
+  double* x = w.lmv + 5 * (size_t)n;
+  double* xn = w.lmv + 6 * (size_t)n;
+  __shared__ double sred[8];
+  __shared__ int sflag;
+  if (w.lmi[3]) {  // a fresh linearisation arrived
+    double c = 0.0;
+    for (int k = threadIdx.x; k < m; k += blockDim.x) c += w.res[k] * w.res[k];
+    c = 0.5 * block_sum(c, sred);
+    double gm = 0.0, xn2 = 0.0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      gm = fmax(gm, fabs(g[j]));
+      xn2 += x[j] * x[j];
+    }
+    gm = block_max(gm, sred);
+    xn2 = block_sum(xn2, sred);
+    if (w.lmi[8])
+      for (int j = threadIdx.x; j < n; j += blockDim.x) scale[j] = 1.0 / (1.0 + sqrt(w.JtJ[(size_t)j * n + j]));  // Jacobi scaling, fixed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      w.lmc[0] = c;
+      w.lmc[4] = sqrt(xn2);
+      if (w.lmi[8]) w.lmc[7] = c;
+      w.lmi[8] = 0;
+      w.lmi[3] = 0;
+      if (gm <= 1e-10) {  // gradient_tolerance
+        w.lmi[1] = 1;
+        w.lmi[5] = 3;
+      }
+    }
+    __syncthreads();
+    if (w.lmi[1]) return;
+  }
+  if (w.lmi[0] >= 50) {  // max_num_iterations, preint.h:945
+    if (threadIdx.x == 0) { w.lmi[1] = 1; w.lmi[5] = 4; }
+    return;
+  }
+  const double radius = w.lmc[2];
+  if (radius < 1e-32) {
+    if (threadIdx.x == 0) { w.lmi[1] = 1; w.lmi[5] = 5; }
+    return;
+  }
+  if (threadIdx.x == 0) w.lmi[0] += 1;
+  if (!w.lmi[2])
+    for (int j = threadIdx.x; j < n; j += blockDim.x) diag[j] = fmin(fmax(w.JtJ[(size_t)j * n + j] * scale[j] * scale[j], 1e-6), 1e32);
+  __syncthreads();
+  double* L = w.lhs;
+  for (size_t q = threadIdx.x; q < (size_t)n * n; q += blockDim.x) {
+    const int i = (int)(q / n), j = (int)(q % n);
+    if (j <= i) L[q] = w.JtJ[q] * scale[i] * scale[j] + (i == j ? diag[i] / radius : 0.0);
+  }
+  for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = g[j] * scale[j];
+  __syncthreads();
+  bool valid = block_cholesky(L, n, n, &sflag);
+  if (valid) {
+    block_chol_solve(L, n, n, step);
+    double bad = 0.0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      step[j] = -step[j];
+      if (!isfinite(step[j])) bad = 1.0;
+      delta[j] = step[j] * scale[j];
+    }
+    bad = block_max(bad, sred);
+    valid = bad == 0.0;
+  }
+  double mcc = 0.0, sn = 0.0;
+  if (valid) {  // model cost change -(J d)^T (r + J d / 2) = -(d.g + d^T (J^T J) d / 2)
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      double t = 0.0;
+      for (int j = 0; j < n; ++j) t += w.JtJ[(size_t)i * n + j] * delta[j];
+      acc += delta[i] * (g[i] + 0.5 * t);
+      sn += delta[i] * delta[i];
+      xn[i] = x[i] + delta[i];
+    }
+    mcc = -block_sum(acc, sred);
+    sn = sqrt(block_sum(sn, sred));
+    if (!(mcc > 0.0)) valid = false;
+  }
+  if (threadIdx.x == 0) {
+    w.lmi[4] = valid ? 1 : 0;
+    w.lmc[5] = mcc;
+    w.lmc[6] = sn;
+  }
+}
+
+// After the candidate residuals: cost, tolerances, acceptance, radius update.  grid: (windows), block 256.
+__global__ __launch_bounds__(256) void lm_decide_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0 || w.lmi[1]) return;
+  const int n = 3 * w.S;
+  const int problem = w.lmi[7];
+  const int m = problem == 0 ? 3 * w.S + 3 * w.G : 3 * w.V + 3 * w.S;
+  __shared__ double sred[8];
+  if (!w.lmi[4]) {  // StepIsInvalid
+    if (threadIdx.x == 0) {
+      w.lmc[2] = w.lmc[2] / w.lmc[3];
+      w.lmc[3] *= 2.0;
+      w.lmi[2] = 1;
+    }
+    return;
+  }
+  double c = 0.0;
+  for (int k = threadIdx.x; k < m; k += blockDim.x) c += w.res_new[k] * w.res_new[k];
+  const double cost_new = 0.5 * block_sum(c, sred);
+  const double cost = w.lmc[0];
+  int accept = 0;
+  if (threadIdx.x == 0) {
+    w.lmc[1] = cost_new;
+    const double cost_change = cost - cost_new;
+    if (w.lmc[6] <= 1e-8 * (w.lmc[4] + 1e-8)) {  // parameter_tolerance
+      w.lmi[1] = 1;
+      w.lmi[5] = 2;
+    } else if (fabs(cost_change) <= 1e-10 * cost) {  // function_tolerance, preint.h:948
+      w.lmi[1] = 1;
+      w.lmi[5] = 1;
+    } else {
+      const double rho = cost_change / w.lmc[5];
+      if (rho > 1e-3) {  // min_relative_decrease
+        accept = 1;
+        w.lmi[6] += 1;
+        w.lmi[3] = 1;
+        w.lmc[2] = fmin(1e16, w.lmc[2] / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3)));
+        w.lmc[3] = 2.0;
+        w.lmi[2] = 0;
+      } else {
+        w.lmc[2] = w.lmc[2] / w.lmc[3];
+        w.lmc[3] *= 2.0;
+        w.lmi[2] = 1;
+      }
+    }
+    sred[7] = (double)accept;
+  }
+  __syncthreads();
+  if (sred[7] != 0.0)
+    for (int j = threadIdx.x; j < n; j += blockDim.x) w.lmv[5 * (size_t)n + j] = w.lmv[6 * (size_t)n + j];
+}
+
+// write the solution back into the state.  grid: (windows), block 256.
+__global__ __launch_bounds__(256) void lm_end_kernel(const UgpmWin* __restrict__ wins, int problem, double* __restrict__ diag_out /* [windows][4] */) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0) return;
+  const int n = 3 * w.S;
+  double* dst = problem == 0 ? w.s_dr : w.s_vel;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) dst[j] = w.lmv[5 * (size_t)n + j];
+  if (threadIdx.x == 0) {
+    diag_out[blockIdx.x * 4 + problem * 2 + 0] = (double)w.lmi[0];
+    diag_out[blockIdx.x * 4 + problem * 2 + 1] = w.lmc[0];
+  }
+}
+
+// =============================================================================================== state correlation
+
+// A = J^T J + 1e-5 I = L L^T, L^-1, dsc = state_std / sqrt(diag(A^-1)) (preint.h:1478-1492).  grid: (windows), block 1024.
+__global__ __launch_bounds__(1024) void corr_factor_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0 || !w.correlate) return;
+  const int n = 6 * w.S;
+  __shared__ int sflag;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) w.Ac[(size_t)i * n + i] += 0.00001;
+  __syncthreads();
+  if (!block_cholesky(w.Ac, n, n, &sflag)) {
+    if (threadIdx.x == 0) *w.status = -6;
+    return;
+  }
+  block_tri_inverse(w.Ac, w.Linv, n, n);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double s = 0.0;
+    for (int k = i; k < n; ++k) {
+      const double l = w.Linv[(size_t)k * n + i];
+      s += l * l;
+    }
+    w.dsc[i] = w.sstd[i] * (1.0 / sqrt(s));
+  }
+}
+
+// =============================================================================================== inference tables + get(t)
+
+// preint.h:978-1060 and finishStateDiff (preint.h:1401-1441).  grid: (windows), block 256.
+__global__ __launch_bounds__(256) void finish_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.x];
+  if (*w.status != 0) return;
+  const int S = w.S;
+  for (int q = threadIdx.x; q < 6 * S; q += blockDim.x) {  // alpha = K^-1 s
+    const int c = q / S, i = q % S;
+    const double* s = c < 3 ? w.s_dr + (size_t)c * S : w.s_vel + (size_t)(c - 3) * S;
+    w.alpha[q] = row_dot(w.Kinv + ((size_t)c * S + i) * S, s, S);
+  }
+  for (int q = threadIdx.x; q < 3 * S; q += blockDim.x) {  // state_r = K_int K^-1 s + dt mean (preint.h:1005, 1410)
+    const int a = q / S, i = q % S;
+    w.state_r[q] = row_dot(w.KintKinv + ((size_t)a * S + i) * S, w.s_dr + (size_t)a * S, S) + (w.state_t[i] - w.start_t) * w.hyper[a * 4 + 3];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {  // finishStateDiff
+    const V3 ri = v3(w.state_r[i], w.state_r[S + i], w.state_r[2 * S + i]);
+    const M3 Ji = JrInv(ri);
+    const V3 d_r = mvec(Ji, load3(w.d_r_dt_local + (size_t)i * 3));
+    const V3 temp_r = ri + mvec(Ji, load3(w.delta_r_time + (size_t)i * 3));
+    const V3 dd = (1.0 / kDt) * (mvec(JrInv(temp_r), load3(w.d_r_dt_local_shift + (size_t)i * 3)) - d_r);
+    w.d_d_r_dt[i] = dd.x; w.d_d_r_dt[S + i] = dd.y; w.d_d_r_dt[2 * S + i] = dd.z;
+    for (int ax = 0; ax < 3; ++ax) {
+      const V3 trw = ri + mvec(Ji, load3(w.delta_r_bw + ((size_t)ax * S + i) * 3));
+      const V3 t = (1.0 / kBw) * (mvec(JrInv(trw), load3(w.d_r_bw_local_shift + ((size_t)ax * S + i) * 3)) - d_r);
+      w.d_state_bw[((size_t)0 * S + i) * 3 + ax] = t.x;
+      w.d_state_bw[((size_t)1 * S + i) * 3 + ax] = t.y;
+      w.d_state_bw[((size_t)2 * S + i) * 3 + ax] = t.z;
+    }
+  }
+  __syncthreads();
+  // delta_R_dt_start (preint.h:1024-1031)
+  __shared__ double srd[3];
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    double s = 0.0;
+    for (int j = 0; j < S; ++j) s += se_kint(w.start_t, w.start_t + kDt, w.state_t[j], w.hyper[c * 4], w.hyper[c * 4 + 1]) * w.alpha[c * S + j];
+    srd[c] = s + kDt * w.hyper[c * 4 + 3];
+  }
+  __syncthreads();
+  const M3 dRt = mtr(expMap(v3(srd[0], srd[1], srd[2])));
+  const V3 mean_vel = v3(w.hyper[15], w.hyper[19], w.hyper[23]);
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {  // preint.h:1035-1060
+    const V3 ri = v3(w.state_r[i], w.state_r[S + i], w.state_r[2 * S + i]);
+    const M3 R = expMap(ri);
+    M3 drbw;  // rows = K_int K^-1 d_state_bw (preint.h:1009-1017), 3 x 3 per state
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+        const double* row = w.KintKinv + ((size_t)a * S + i) * S;
+        for (int j = 0; j < S; ++j) s += row[j] * w.d_state_bw[((size_t)a * S + j) * 3 + c];
+        drbw.m[a * 3 + c] = s;
+      }
+    const V3 sv = v3(w.s_vel[i], w.s_vel[S + i], w.s_vel[2 * S + i]) + mean_vel;
+    const M3 dvbw = mmul(mmul(skew(sv), Jr(v3(-ri.x, -ri.y, -ri.z))), drbw);  // negated below (preint.h:1048)
+    const V3 dvdt = (1.0 / kDt) * (mvec(dRt, sv) - sv);
+    const double dv[3] = {dvdt.x, dvdt.y, dvdt.z};
+    for (int a = 0; a < 3; ++a) {
+      for (int c = 0; c < 3; ++c) {
+        w.d_vel_bv[((size_t)a * S + i) * 3 + c] = R.m[a * 3 + c];
+        w.d_vel_bw[((size_t)a * S + i) * 3 + c] = -dvbw.m[a * 3 + c];
+      }
+      w.d_vel_dt[a * S + i] = dv[a];
+    }
+  }
+}
+
+// Se3Integrator::get(t) (preint.h:1069-1153) + cov inflation of VelPreintegration::get (preint.h:1744-1757).
+// grid: (max n_infer, windows), block 256.
+__global__ __launch_bounds__(256) void infer_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.y];
+  const int qi = blockIdx.x;
+  if (qi >= w.n_infer) return;
+  double* out = w.out + (size_t)qi * 83;
+  if (*w.status != 0) {
+    for (int k = threadIdx.x; k < 83; k += blockDim.x) out[k] = __longlong_as_double(0x7ff8000000000000LL);
+    return;
+  }
+  const int S = w.S, n = 6 * S;
+  const double t = w.infer_t[qi], dt = t - w.start_t;
+  __shared__ double ksK[6][160];  // ks K^-1 per channel
+  __shared__ double sval[6][8];   // per channel: 0 ks.alpha, 1 ks K^-1 ks^T, 2 d_r_dt / (ks_dt.alpha + ksK.d_vel_dt), 3..5 d/d bw, 6..8 -> second array
+  __shared__ double sval2[6][4];
+  __shared__ double sred[8];
+  __shared__ double scov[36];
+  for (int q = threadIdx.x; q < 6 * S; q += blockDim.x) {
+    const int c = q / S, j = q % S;
+    double s = 0.0;
+    for (int k = 0; k < S; ++k) s += se_kint(w.start_t, t, w.state_t[k], w.hyper[c * 4], w.hyper[c * 4 + 1]) * w.Kinv[((size_t)c * S + k) * S + j];
+    ksK[c][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int c = threadIdx.x;
+    const double l2 = w.hyper[c * 4], sf2 = w.hyper[c * 4 + 1];
+    double ka = 0.0, kKk = 0.0, e2 = 0.0, bw[3] = {0, 0, 0}, bv[3] = {0, 0, 0};
+    for (int j = 0; j < S; ++j) {
+      const double ks = se_kint(w.start_t, t, w.state_t[j], l2, sf2);
+      ka += ks * w.alpha[c * S + j];
+      kKk += ksK[c][j] * ks;
+      if (c < 3) {
+        e2 += ksK[c][j] * w.d_d_r_dt[c * S + j];
+        for (int q = 0; q < 3; ++q) bw[q] += ksK[c][j] * w.d_state_bw[((size_t)c * S + j) * 3 + q];
+      } else {
+        e2 += se_kint_dt(w.start_t, t, w.state_t[j], l2, sf2) * w.alpha[c * S + j] + ksK[c][j] * w.d_vel_dt[(c - 3) * S + j];
+        for (int q = 0; q < 3; ++q) {
+          bw[q] += ksK[c][j] * w.d_vel_bw[((size_t)(c - 3) * S + j) * 3 + q];
+          bv[q] += ksK[c][j] * w.d_vel_bv[((size_t)(c - 3) * S + j) * 3 + q];
+        }
+      }
+    }
+    double var = kss_int(w.start_t, t, l2, sf2) - kKk;
+    if (var <= 0) var = dt * dt * w.hyper[c * 4 + 2];
+    sval[c][0] = ka + dt * w.hyper[c * 4 + 3];
+    sval[c][1] = var;
+    sval[c][2] = e2;
+    for (int q = 0; q < 3; ++q) {
+      sval[c][3 + q] = bw[q];
+      sval2[c][q] = bv[q];
+    }
+  }
+  __syncthreads();
+  // covariance: cov_ab = ks_a C_ab ks_b^T with C = D A^-1 D  =>  (L^-1 u_a) . (L^-1 u_b), u_a = dsc .* ksK_a placed in block a
+  if (w.correlate) {
+    for (int pair = 0; pair < 21; ++pair) {
+      int a = 0, b = pair;
+      while (b >= 6 - a) { b -= 6 - a; ++a; }
+      b += a;
+      double acc = 0.0;
+      for (int k = threadIdx.x; k < n; k += blockDim.x) {  // y_a[k] = sum_{i in block a, i <= k} Linv[k][i] u_a[i]
+        double ya = 0.0, yb = 0.0;
+        const double* row = w.Linv + (size_t)k * n;
+        const int ea = min(k + 1, (a + 1) * S), eb = min(k + 1, (b + 1) * S);
+        for (int i = a * S; i < ea; ++i) ya += row[i] * w.dsc[i] * ksK[a][i - a * S];
+        if (b == a) yb = ya;
+        else
+          for (int i = b * S; i < eb; ++i) yb += row[i] * w.dsc[i] * ksK[b][i - b * S];
+        acc += ya * yb;
+      }
+      acc = block_sum(acc, sred);
+      if (threadIdx.x == 0) {
+        scov[a * 6 + b] = acc;
+        scov[b * 6 + a] = acc;
+      }
+    }
+  } else {
+    if (threadIdx.x < 36) scov[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      const int a = threadIdx.x;
+      double s = 0.0;
+      for (int j = 0; j < S; ++j) s += ksK[a][j] * w.var[a * S + j] * ksK[a][j];
+      scov[a * 6 + a] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const V3 r = v3(sval[0][0], sval[1][0], sval[2][0]);
+    const M3 jr = Jr(r);
+    const M3 R = expMap(r);
+    M3 d_r_dw, d_p_dw, d_p_dv;
+    for (int a = 0; a < 3; ++a)
+      for (int q = 0; q < 3; ++q) {
+        d_r_dw.m[a * 3 + q] = sval[a][3 + q];
+        d_p_dw.m[a * 3 + q] = sval[3 + a][3 + q];
+        d_p_dv.m[a * 3 + q] = sval2[3 + a][q];
+      }
+    storeM(out, R);
+    out[9] = sval[3][0]; out[10] = sval[4][0]; out[11] = sval[5][0];
+    out[12] = dt;
+    out[13] = 0.5 * dt * dt;
+    double cov[36], td[6];
+    for (int a = 0; a < 6; ++a) td[a] = sqrt(sval[a][1]) * (1.0 / sqrt(scov[a * 6 + a]));  // preint.h:1141-1145
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) cov[a * 6 + b] = scov[a * 6 + b] * td[a] * td[b];
+    M3 c00, c03;  // preint.h:1148-1150
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        c00.m[a * 3 + b] = cov[a * 6 + b];
+        c03.m[a * 3 + b] = cov[a * 6 + 3 + b];
+      }
+    const M3 n00 = mmul(mmul(jr, c00), mtr(jr)), n03 = mmul(jr, c03);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        cov[a * 6 + b] = n00.m[a * 3 + b];
+        cov[a * 6 + 3 + b] = n03.m[a * 3 + b];
+        cov[(3 + b) * 6 + a] = n03.m[a * 3 + b];
+      }
+    if (w.vel_bias_std > 0.0 || w.gyr_bias_std > 0.0) {  // preint.h:1744-1757
+      double J[36];
+      for (int q = 0; q < 36; ++q) J[q] = 0.0;
+      const double g2 = w.gyr_bias_std * w.gyr_bias_std, v2 = w.vel_bias_std * w.vel_bias_std;
+      const double bc[6] = {g2, g2, g2, v2, v2, v2};
+      for (int a = 0; a < 3; ++a) {
+        J[a * 6 + a] = 1.0;
+        for (int b = 0; b < 3; ++b) {
+          J[(3 + a) * 6 + b] = d_p_dw.m[a * 3 + b];
+          J[(3 + a) * 6 + 3 + b] = d_p_dv.m[a * 3 + b];
+        }
+      }
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+          double s = 0.0;
+          for (int k = 0; k < 6; ++k) s += J[a * 6 + k] * bc[k] * J[b * 6 + k];
+          cov[a * 6 + b] += s;
+        }
+    }
+    for (int q = 0; q < 36; ++q) out[14 + q] = cov[q];
+    storeM(out + 50, mmul(jr, d_r_dw));
+    store3(out + 59, mvec(jr, v3(sval[0][2], sval[1][2], sval[2][2])));
+    storeM(out + 62, d_p_dw);
+    storeM(out + 71, d_p_dv);
+    out[80] = sval[3][2]; out[81] = sval[4][2]; out[82] = sval[5][2];
+  }
+}
+
+}  // namespace ug
+}  // namespace gorio

@@ -29,6 +29,8 @@ def test_binding_covers_header(gorio):
 
     apd = import_module("go-rio_amd.apd")
     assert sorted(apd.APD_SYMBOLS) == _declared("gorio_apd.h")
+    ugpm = import_module("go-rio_amd.ugpm")
+    assert sorted(ugpm.UGPM_SYMBOLS) == _declared("gorio_ugpm.h")
 
 
 def test_default_params_match_reference_defaults(gorio):
