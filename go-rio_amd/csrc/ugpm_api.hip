@@ -89,7 +89,7 @@ size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* b
   u.KsKinv = take(3 * G * S); u.KsIntKinv = take(3 * G * S); u.KgyrIntKinv = take(3 * V * S); u.KvelKinv = take(3 * V * S);
   u.Jrot = take(mrot * n); u.Jvel = take(mvel * n); u.res = take(std::max(mrot, mvel)); u.res_new = take(std::max(mrot, mvel));
   u.JtJ = take(n * n); u.lhs = take(n * n); u.lmv = take(8 * n); u.sample_tmp = take(std::max(G, V) * 24);
-  if (w.correlate) { u.Jc = take(mc * nc); u.Ac = take(nc * nc); u.Linv = take(nc * nc); }
+  if (w.correlate) { u.Jc = take(mc * nc); u.Ac = take(nc * nc); }
   u.dsc = take(nc);
   u.alpha = take(6 * S); u.state_r = take(3 * S); u.d_state_bw = take(3 * S * 3); u.d_d_r_dt = take(3 * S); u.d_vel_bv = take(3 * S * 3); u.d_vel_bw = take(3 * S * 3);
   u.d_vel_dt = take(3 * S); u.out = take((size_t)w.n_infer * 83); u.lmc = take(16);
@@ -289,7 +289,8 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       Stage st(c, 2);  // state correlation at the LPM-initialised state (a side thread in the reference, preint.h:939)
       ug::corr_jac_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
       ug::ata_kernel<<<dim3(tiles_c, tiles_c, nw), 256, 0, c.stream>>>(c.d_wins, 2);
-      ug::corr_factor_kernel<<<nw, 1024, 0, c.stream>>>(c.d_wins);
+      ug::corr_factor_kernel<<<nw, 512, 0, c.stream>>>(c.d_wins);
+      ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, nw), 256, sizeof(double) * 17 * 6 * max_S, c.stream>>>(c.d_wins);
     }
     std::vector<int> flags(17 * (size_t)nw);
     for (int problem = 0; problem < 2; ++problem) {  // ceres::Solve #1 (rotation) and #2 (velocity), preint.h:943-967
@@ -319,7 +320,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     {
       Stage st(c, 4);
       ug::finish_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
-      ug::infer_kernel<<<dim3(std::max(1, max_infer), nw), 256, 0, c.stream>>>(c.d_wins);
+      ug::infer_kernel<<<dim3(std::max(1, max_infer), nw), 256, sizeof(double) * 7 * 6 * max_S, c.stream>>>(c.d_wins);
     }
     UHIP(hipGetLastError());
   }

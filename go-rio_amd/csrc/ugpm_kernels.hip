@@ -7,9 +7,9 @@
 //   cross_kernel         K_s K^-1 / K_s_int K^-1 tables of the two cost functions           cost_functions.h:183-190, 293-308
 //   rot_eval / vel_eval  residuals and analytic Jacobians of GpNorm + Rot / Vel cost functions         cost_functions.h:14-385
 //   corr_jac_kernel      stacked Jacobian of the state-correlation step                                   preint.h:887-937
-//   ata_kernel           J^T J (+ J^T r): LDS-tiled fp64 rank-k update, symmetric tiles only
+//   ata_kernel           J^T J (+ J^T r) on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), symmetric tiles only
 //   lm_step / lm_decide  Ceres-style trust-region Levenberg-Marquardt (normal equations, Cholesky in HBM/L2)  preint.h:943-967
-//   corr_factor_kernel   (J^T J + 1e-5 I) = L L^T, L^-1, diag(A^-1), correlation scaling                preint.h:1478-1492
+//   corr_factor_kernel   (J^T J + 1e-5 I) = L L^T; corr_diag_kernel: diag(A^-1), correlation scaling   preint.h:1478-1492
 //   finish_kernel        alpha = K^-1 s, post-integration Jacobian tables                        preint.h:978-1060, 1401-1441
 //   infer_kernel         Se3Integrator::get(t) + the bias-prior inflation of VelPreintegration::get    preint.h:1069-1153, 1744-1757
 //
@@ -423,73 +423,177 @@ __global__ __launch_bounds__(320) void lpm_init_kernel(const UgpmWin* __restrict
 
 // =============================================================================================== block-wide dense helpers
 
-// in-place lower Cholesky of the n x n matrix A (row-major, leading dimension lda) by one workgroup; returns false on a
-// non-positive pivot.  Right-looking, column at a time; the upper triangle is not referenced.
-__device__ bool block_cholesky(double* __restrict__ A, int n, int lda, int* __restrict__ sflag) {
+// In-place lower Cholesky of the n x n matrix A (row-major, leading dimension lda, resident in HBM / L2) by one workgroup.
+// Right-looking, blocked by 16 columns: the 16 x 16 diagonal block is factored in LDS, the panel below is solved against it one
+// row per lane and kept in LDS, and the trailing update A22 -= P P^T runs as 4 x 4 register tiles fed from LDS -- the only
+// global traffic is one read-modify-write sweep of the trailing triangle per block column.  Returns false on a non-positive
+// pivot.  The upper triangle is never referenced.  n <= kCholMaxN.
+constexpr int kCholNB = 16;
+constexpr int kCholMaxN = 6 * 160;
+struct CholLds {
+  double D[kCholNB][kCholNB + 1];
+  double P[kCholMaxN > 384 ? 384 : kCholMaxN][kCholNB + 1];  // panel rows of the current block column (n - kb - NB <= 384 rows handled per pass)
+};
+
+__device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, int lda, CholLds& L, int* __restrict__ sflag) {
+  constexpr int NB = kCholNB;
   if (threadIdx.x == 0) *sflag = 0;
   __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    const double ajj = A[(size_t)j * lda + j];
-    if (!(ajj > 0.0)) {
-      if (threadIdx.x == 0) *sflag = 1;
+  for (int kb = 0; kb < n; kb += NB) {
+    const int nb = min(NB, n - kb);
+    for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
+      const int r = q / nb, c = q % nb;
+      if (c <= r) L.D[r][c] = A[(size_t)(kb + r) * lda + kb + c];
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {  // unblocked factorisation of the diagonal block in LDS
+      const double ajj = L.D[j][j];
       __syncthreads();
-      return false;
+      if (!(ajj > 0.0)) {
+        if (threadIdx.x == 0) *sflag = 1;
+        __syncthreads();
+        return false;
+      }
+      const double d = sqrt(ajj);
+      if (threadIdx.x == 0) L.D[j][j] = d;
+      for (int r = j + 1 + threadIdx.x; r < nb; r += blockDim.x) L.D[r][j] /= d;
+      __syncthreads();
+      const int m2 = nb - j - 1;
+      for (int q = threadIdx.x; q < m2 * m2; q += blockDim.x) {
+        const int r = j + 1 + q / m2, c = j + 1 + q % m2;
+        if (c <= r) L.D[r][c] -= L.D[r][j] * L.D[c][j];
+      }
+      __syncthreads();
     }
-    const double d = sqrt(ajj);
-    __syncthreads();
-    for (int i = j + threadIdx.x; i < n; i += blockDim.x) A[(size_t)i * lda + j] = (i == j) ? d : A[(size_t)i * lda + j] / d;
-    __syncthreads();
-    // trailing update of the lower triangle: A[i][k] -= L[i][j] L[k][j], j < k <= i
-    const int m = n - j - 1;
-    const long cnt = (long)m * (m + 1) / 2;
-    for (long q = threadIdx.x; q < cnt; q += blockDim.x) {
-      // unrank q -> (r, c) with 0 <= c <= r < m
-      int r = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-      while ((long)r * (r + 1) / 2 > q) --r;
-      while ((long)(r + 1) * (r + 2) / 2 <= q) ++r;
-      const int c = (int)(q - (long)r * (r + 1) / 2);
-      const int i = j + 1 + r, k = j + 1 + c;
-      A[(size_t)i * lda + k] -= A[(size_t)i * lda + j] * A[(size_t)k * lda + j];
+    for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
+      const int r = q / nb, c = q % nb;
+      if (c <= r) A[(size_t)(kb + r) * lda + kb + c] = L.D[r][c];
     }
-    __syncthreads();
+    const int m = n - kb - nb;  // rows below the diagonal block
+    if (m <= 0) break;
+    for (int p0 = 0; p0 < m; p0 += 384) {  // panel passes (one pass unless n > 400)
+      const int mp = min(384, m - p0);
+      for (int i = threadIdx.x; i < mp; i += blockDim.x) {  // panel solve: row i of L21 = A21 L11^-T
+        double* arow = A + (size_t)(kb + nb + p0 + i) * lda + kb;
+        double x[NB];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+          if (c < nb) {
+            double v = arow[c];
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+              if (q < c) v -= x[q] * L.D[c][q];
+            v /= L.D[c][c];
+            x[c] = v;
+            arow[c] = v;
+            L.P[i][c] = v;
+          } else {
+            x[c] = 0.0;
+            L.P[i][c] = 0.0;
+          }
+        }
+      }
+      __syncthreads();
+      // trailing update restricted to rows of this pass: A[i][k] -= P[i] . P[k] for kb+nb <= k <= i.  Columns k that belong to
+      // an earlier pass need their panel rows too, so with more than one pass we fall back to reading L21 from A.
+      const int T = (mp + 3) / 4;
+      const long ntile = (p0 == 0) ? (long)T * (T + 1) / 2 : 0;
+      for (long q = threadIdx.x; q < ntile; q += blockDim.x) {
+        int tr = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+        while ((long)tr * (tr + 1) / 2 > q) --tr;
+        while ((long)(tr + 1) * (tr + 2) / 2 <= q) ++tr;
+        const int tc = (int)(q - (long)tr * (tr + 1) / 2);
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+          double pr[4], pc[4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            pr[a] = (tr * 4 + a < mp) ? L.P[tr * 4 + a][c] : 0.0;
+            pc[a] = (tc * 4 + a < mp) ? L.P[tc * 4 + a][c] : 0.0;
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += pr[a] * pc[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int i = tr * 4 + a, k = tc * 4 + b;
+            if (i < mp && k <= i) A[(size_t)(kb + nb + i) * lda + kb + nb + k] -= acc[a][b];
+          }
+      }
+      if (p0 != 0 || m > 384) {  // generic (slow) path for matrices larger than one panel pass: element-wise from global memory
+        for (long q = threadIdx.x; q < (long)mp * m; q += blockDim.x) {
+          const int i = p0 + (int)(q / m), k = (int)(q % m);
+          if (k > i || (p0 == 0 && k < mp)) continue;
+          double sacc = 0.0;
+          for (int c = 0; c < nb; ++c) sacc += A[(size_t)(kb + nb + i) * lda + kb + c] * A[(size_t)(kb + nb + k) * lda + kb + c];
+          A[(size_t)(kb + nb + i) * lda + kb + nb + k] -= sacc;
+        }
+      }
+      __syncthreads();
+    }
   }
+  __syncthreads();
   return true;
 }
 
-// Linv = L^-1 (lower triangular), one column per thread (forward substitution against e_col)
-__device__ void block_tri_inverse(const double* __restrict__ L, double* __restrict__ Li, int n, int lda) {
-  for (int col = threadIdx.x; col < n; col += blockDim.x) {
-    for (int i = 0; i < col; ++i) Li[(size_t)i * lda + col] = 0.0;
-    Li[(size_t)col * lda + col] = 1.0 / L[(size_t)col * lda + col];
-    for (int i = col + 1; i < n; ++i) {
-      double s = 0.0;
-      for (int k = col; k < i; ++k) s -= L[(size_t)i * lda + k] * Li[(size_t)k * lda + col];
-      Li[(size_t)i * lda + col] = s / L[(size_t)i * lda + i];
+// Forward substitution L X = B for NC right-hand sides by ONE wave, X / B held in LDS as X[row * ldx + col].  Lanes split the
+// dot product of a row (coalesced reads of the L row from HBM / L2), a shuffle tree reduces it, lane 0 finishes the row.
+// No workgroup barrier is involved, so several waves can solve different column groups of the same system concurrently.
+// Rows < row0 of B must be zero (they are skipped).
+template <int NC>
+__device__ __forceinline__ void wave_forward(const double* __restrict__ L, int n, int lda, double* __restrict__ X, int ldx, int row0) {
+  const int lane = threadIdx.x & 63;
+  for (int i = row0; i < n; ++i) {
+    const double* Lr = L + (size_t)i * lda;
+    double acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+    for (int k = row0 + lane; k < i; k += 64) {
+      const double l = Lr[k];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] += l * X[(size_t)k * ldx + c];
     }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_down(acc[c], off, 64);
+    }
+    if (lane == 0) {
+      const double d = Lr[i];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) X[(size_t)i * ldx + c] = (X[(size_t)i * ldx + c] - acc[c]) / d;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  __syncthreads();
 }
 
-// x = (L L^T)^-1 b with the column-oriented substitution (all threads update the remaining right-hand side)
-__device__ void block_chol_solve(const double* __restrict__ L, int n, int lda, double* __restrict__ x /* in: b, out: x */) {
-  for (int j = 0; j < n; ++j) {
-    __syncthreads();
-    const double xj = x[j] / L[(size_t)j * lda + j];
-    __syncthreads();
-    if (threadIdx.x == 0) x[j] = xj;
-    for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) x[i] -= L[(size_t)i * lda + j] * xj;
+// Backward substitution L^T x = y (one right-hand side, in place in LDS) by one wave
+__device__ __forceinline__ void wave_backward(const double* __restrict__ L, int n, int lda, double* __restrict__ x) {
+  const int lane = threadIdx.x & 63;
+  for (int i = n - 1; i >= 0; --i) {
+    double acc = 0.0;
+    for (int k = i + 1 + lane; k < n; k += 64) acc += L[(size_t)k * lda + i] * x[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) x[i] = (x[i] - acc) / L[(size_t)i * lda + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  for (int j = n - 1; j >= 0; --j) {
-    __syncthreads();
-    const double xj = x[j] / L[(size_t)j * lda + j];
-    __syncthreads();
-    if (threadIdx.x == 0) x[j] = xj;
-    for (int i = threadIdx.x; i < j; i += blockDim.x) x[i] -= L[(size_t)j * lda + i] * xj;
-  }
-  __syncthreads();
 }
 
-__device__ double block_sum(double v, double* sred) {
+__device__ __forceinline__ double block_sum(double v, double* sred) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   __syncthreads();
@@ -499,7 +603,7 @@ __device__ double block_sum(double v, double* sred) {
   for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += sred[q];
   return t;
 }
-__device__ double block_max(double v, double* sred) {
+__device__ __forceinline__ double block_max(double v, double* sred) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
   __syncthreads();
@@ -522,16 +626,36 @@ __global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ w
   double* B = w.KKinv + (size_t)c * S * S;   // L^-1 scratch -> finally K K^-1
   const double* st = w.state_t;
   __shared__ int sflag;
+  __shared__ CholLds chol;
   for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
     const int i = q / S, j = q % S;
     A[q] = se_k(st[i], st[j], l2, sf2) + (i == j ? sz2 : 0.0);
   }
   __syncthreads();
-  if (!block_cholesky(A, S, S, &sflag)) {
+  if (!block_cholesky(A, S, S, chol, &sflag)) {
     if (threadIdx.x == 0) *w.status = -6;
     return;
   }
-  block_tri_inverse(A, B, S, S);
+  // L^-1 column group by column group (4 columns per wave, unit right-hand sides in LDS), stored to B
+  {
+    double (*Xg)[17] = chol.P;  // the panel buffer is free after the factorisation (S <= 160 rows of 17)
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j0 = 0; j0 < S; j0 += 16) {
+      for (int q = threadIdx.x; q < S * 16; q += blockDim.x) {
+        const int i = q / 16, c = q % 16;
+        Xg[i][c] = (i == j0 + c) ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      if (j0 + wv * 4 < S) wave_forward<4>(A, S, S, &Xg[0][wv * 4], 17, j0 + wv * 4);
+      __syncthreads();
+      for (int q = threadIdx.x; q < S * 16; q += blockDim.x) {
+        const int i = q / 16, c = q % 16;
+        if (j0 + c < S) B[(size_t)i * S + j0 + c] = Xg[i][c];
+      }
+      __syncthreads();
+      (void)lane;
+    }
+  }
   // K^-1 = L^-T L^-1 (symmetric): K^-1[i][j] = sum_{k >= max(i,j)} Li[k][i] Li[k][j]
   for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
     const int i = q / S, j = q % S;
@@ -798,9 +922,14 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
 
 // =============================================================================================== J^T J
 
-// C = A^T A for A (m x n, row-major): 64 x 64 output tiles, 16-deep k panels staged through LDS, 256 threads x (4 x 4) fp64
-// accumulators; only tiles with tj >= ti are computed and mirrored.  Optionally g = A^T r (tile row 0 does it).
+// C = A^T A for A (m x n, row-major) on the fp64 matrix cores: v_mfma_f64_16x16x4_f64 takes A^T as its 16 x 4 operand and A as
+// its 4 x 16 operand, and BOTH are plain row segments of A (lane l reads A[k0 + (l >> 4)][c0 + (l & 15)], 128 B contiguous per
+// k-row), so the operands stream straight from L2 into the matrix pipe with no LDS transpose.  One workgroup owns a 64 x 64
+// output tile (4 waves x 32 x 32 = 2 x 2 MFMA tiles each); only tiles with tj >= ti are computed and mirrored.
+// f64 C/D layout (16x16x4): col = lane & 15, row = (lane >> 4) + 4 * reg.   g = A^T r is formed by the tile row ti == 0.
 // grid: (tiles, tiles, windows).  which: 0 rot problem, 1 vel problem, 2 correlation.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void ata_kernel(const UgpmWin* __restrict__ wins, int which) {
   const UgpmWin& w = wins[blockIdx.z];
   if (*w.status != 0) return;
@@ -821,60 +950,53 @@ __global__ __launch_bounds__(256) void ata_kernel(const UgpmWin* __restrict__ wi
   }
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (tj < ti || ti * 64 >= n || tj * 64 >= n) return;
-  __shared__ double sa[16][64], sb[16][64];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double acc[4][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i0 = ti * 64 + (wave >> 1) * 32, j0 = tj * 64 + (wave & 1) * 32;
+  const int lr = lane & 15, lk = lane >> 4;
+  f64x4 acc[2][2];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-  double gacc[4] = {0, 0, 0, 0};
-  const bool do_g = (g != nullptr) && ti == 0 && ty == 0;  // g for the columns of tile column tj, by the 16 threads of ty == 0
-  for (int k0 = 0; k0 < m; k0 += 16) {
-    for (int q = threadIdx.x; q < 16 * 64; q += 256) {
-      const int kk = q >> 6, cc = q & 63;
-      const int k = k0 + kk;
-      const int ci = ti * 64 + cc, cj = tj * 64 + cc;
-      sa[kk][cc] = (k < m && ci < n) ? A[(size_t)k * n + ci] : 0.0;
-      sb[kk][cc] = (k < m && cj < n) ? A[(size_t)k * n + cj] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      double av[4], bv[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) av[a] = sa[kk][ty * 4 + a];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bv[b] = sb[kk][tx * 4 + b];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
-      if (do_g) {
-        const int k = k0 + kk;
-        const double rk = k < m ? r[k] : 0.0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) gacc[b] += bv[b] * rk;
-      }
-    }
-    __syncthreads();
+    for (int q = 0; q < 2; ++q) acc[p][q] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const bool ci0 = i0 + lr < n, ci1 = i0 + 16 + lr < n, cj0 = j0 + lr < n, cj1 = j0 + 16 + lr < n;
+  const double* pa0 = A + i0 + lr;
+  const double* pb0 = A + j0 + lr;
+#pragma unroll 4
+  for (int k0 = 0; k0 < m; k0 += 4) {
+    const int k = k0 + lk;
+    const bool kv = k < m;
+    const size_t ro = (size_t)k * n;
+    const double a0 = (kv && ci0) ? pa0[ro] : 0.0;
+    const double a1 = (kv && ci1) ? pa0[ro + 16] : 0.0;
+    const double b0 = (kv && cj0) ? pb0[ro] : 0.0;
+    const double b1 = (kv && cj1) ? pb0[ro + 16] : 0.0;
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = ti * 64 + ty * 4 + a, j = tj * 64 + tx * 4 + b;
-      if (i < n && j < n) {
-        C[(size_t)i * n + j] = acc[a][b];
-        C[(size_t)j * n + i] = acc[a][b];
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int i = i0 + p * 16 + lk + 4 * rg, j = j0 + q * 16 + lr;
+        if (i < n && j < n) {
+          C[(size_t)i * n + j] = acc[p][q][rg];
+          C[(size_t)j * n + i] = acc[p][q][rg];
+        }
       }
-    }
-  if (do_g)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int j = tj * 64 + tx * 4 + b;
-      if (j < n) g[j] = gacc[b];
-    }
+  if (g != nullptr && ti == 0) {  // g[j] = sum_k A[k][j] r[k] for the 64 columns of tile column tj: 4 k-slices, LDS tree
+    __shared__ double sg[4][64];
+    const int j = tj * 64 + lane;
+    double s = 0.0;
+    if (j < n)
+      for (int k = wave; k < m; k += 4) s += A[(size_t)k * n + j] * r[k];
+    sg[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < n) g[j] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+  }
 }
 
 // =============================================================================================== Levenberg-Marquardt (Ceres 2.1 defaults + preint.h:943-948)
@@ -916,6 +1038,7 @@ __global__ __launch_bounds__(256) void lm_step_kernel(const UgpmWin* __restrict_
   double* xn = w.lmv + 6 * (size_t)n;
   __shared__ double sred[8];
   __shared__ int sflag;
+  __shared__ CholLds chol;
   if (w.lmi[3]) {  // a fresh linearisation arrived
     double c = 0.0;
     for (int k = threadIdx.x; k < m; k += blockDim.x) c += w.res[k] * w.res[k];
@@ -964,9 +1087,18 @@ __global__ __launch_bounds__(256) void lm_step_kernel(const UgpmWin* __restrict_
   }
   for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = g[j] * scale[j];
   __syncthreads();
-  bool valid = block_cholesky(L, n, n, &sflag);
+  bool valid = block_cholesky(L, n, n, chol, &sflag);
   if (valid) {
-    block_chol_solve(L, n, n, step);
+    double* xs = &chol.P[0][0];  // the panel buffer is free again: solve in LDS
+    for (int j = threadIdx.x; j < n; j += blockDim.x) xs[j] = step[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      wave_forward<1>(L, n, n, xs, 1, 0);
+      wave_backward(L, n, n, xs);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = xs[j];
+    __syncthreads();
     double bad = 0.0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
       step[j] = -step[j];
@@ -1065,25 +1197,49 @@ __global__ __launch_bounds__(256) void lm_end_kernel(const UgpmWin* __restrict__
 // =============================================================================================== state correlation
 
 // A = J^T J + 1e-5 I = L L^T, L^-1, dsc = state_std / sqrt(diag(A^-1)) (preint.h:1478-1492).  grid: (windows), block 1024.
-__global__ __launch_bounds__(1024) void corr_factor_kernel(const UgpmWin* __restrict__ wins) {
+__global__ __launch_bounds__(512) void corr_factor_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin& w = wins[blockIdx.x];
   if (*w.status != 0 || !w.correlate) return;
   const int n = 6 * w.S;
   __shared__ int sflag;
+  __shared__ CholLds chol;
   for (int i = threadIdx.x; i < n; i += blockDim.x) w.Ac[(size_t)i * n + i] += 0.00001;
   __syncthreads();
-  if (!block_cholesky(w.Ac, n, n, &sflag)) {
+  if (!block_cholesky(w.Ac, n, n, chol, &sflag)) {
     if (threadIdx.x == 0) *w.status = -6;
     return;
   }
-  block_tri_inverse(w.Ac, w.Linv, n, n);
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    double s = 0.0;
-    for (int k = i; k < n; ++k) {
-      const double l = w.Linv[(size_t)k * n + i];
-      s += l * l;
+}
+
+// diag(A^-1) = column norms of L^-1, 16 columns per workgroup (4 per wave), unit right-hand sides in LDS; then
+// dsc = state_std / sqrt(diag(A^-1)) (preint.h:1487-1489).  grid: (ceil(6S / 16), windows), block 256.
+__global__ __launch_bounds__(256) void corr_diag_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin& w = wins[blockIdx.y];
+  if (*w.status != 0 || !w.correlate) return;
+  const int n = 6 * w.S;
+  const int j0 = blockIdx.x * 16;
+  if (j0 >= n) return;
+  extern __shared__ double Xc[];  // [n][17]
+  for (int q = threadIdx.x; q < n * 16; q += blockDim.x) {
+    const int i = q / 16, c = q % 16;
+    Xc[(size_t)i * 17 + c] = (i == j0 + c) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (j0 + wv * 4 < n) {
+    wave_forward<4>(w.Ac, n, n, Xc + wv * 4, 17, j0 + wv * 4);
+    for (int c = 0; c < 4; ++c) {
+      const int col = j0 + wv * 4 + c;
+      if (col >= n) break;
+      double s = 0.0;
+      for (int i = col + lane; i < n; i += 64) {
+        const double v = Xc[(size_t)i * 17 + wv * 4 + c];
+        s += v * v;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+      if (lane == 0) w.dsc[col] = w.sstd[col] * (1.0 / sqrt(s));
     }
-    w.dsc[i] = w.sstd[i] * (1.0 / sqrt(s));
   }
 }
 
@@ -1213,21 +1369,23 @@ __global__ __launch_bounds__(256) void infer_kernel(const UgpmWin* __restrict__ 
   __syncthreads();
   // covariance: cov_ab = ks_a C_ab ks_b^T with C = D A^-1 D  =>  (L^-1 u_a) . (L^-1 u_b), u_a = dsc .* ksK_a placed in block a
   if (w.correlate) {
+    extern __shared__ double Yc[];  // [n][7]: columns = L^-1 u_a
+    for (int q = threadIdx.x; q < n * 6; q += blockDim.x) {
+      const int i = q / 6, a = q % 6;
+      Yc[(size_t)i * 7 + a] = (i / S == a) ? w.dsc[i] * ksK[a][i - a * S] : 0.0;
+    }
+    __syncthreads();
+    {
+      const int wv = threadIdx.x >> 6;
+      if (wv < 3) wave_forward<2>(w.Ac, n, n, Yc + wv * 2, 7, wv * 2 * S);  // u_a is zero above row a S
+    }
+    __syncthreads();
     for (int pair = 0; pair < 21; ++pair) {
       int a = 0, b = pair;
       while (b >= 6 - a) { b -= 6 - a; ++a; }
       b += a;
       double acc = 0.0;
-      for (int k = threadIdx.x; k < n; k += blockDim.x) {  // y_a[k] = sum_{i in block a, i <= k} Linv[k][i] u_a[i]
-        double ya = 0.0, yb = 0.0;
-        const double* row = w.Linv + (size_t)k * n;
-        const int ea = min(k + 1, (a + 1) * S), eb = min(k + 1, (b + 1) * S);
-        for (int i = a * S; i < ea; ++i) ya += row[i] * w.dsc[i] * ksK[a][i - a * S];
-        if (b == a) yb = ya;
-        else
-          for (int i = b * S; i < eb; ++i) yb += row[i] * w.dsc[i] * ksK[b][i - b * S];
-        acc += ya * yb;
-      }
+      for (int k = threadIdx.x; k < n; k += blockDim.x) acc += Yc[(size_t)k * 7 + a] * Yc[(size_t)k * 7 + b];
       acc = block_sum(acc, sred);
       if (threadIdx.x == 0) {
         scov[a * 6 + b] = acc;

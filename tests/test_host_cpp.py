@@ -65,7 +65,7 @@ def test_nodelet_call_sequence_matches_python_binding(gpu, gorio, tmp_path, pose
         fit, _ = g.getFitnessScore(res["T"])
         assert out["fitness"] == pytest.approx(fit, rel=1e-12)
         moved = g.transformSource(res["T"])
-        assert np.allclose(out["aligned0"], moved[0], rtol=0, atol=0)
+        assert np.array_equal(np.array(out["aligned0"], np.float32), moved[0])
         assert out["label0"] == frames[k][1][0]  # normal_x label is carried through untouched (LSQ:79)
         if res["converged"]:
             prev = res["T"]
