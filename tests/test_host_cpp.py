@@ -72,3 +72,41 @@ def test_nodelet_call_sequence_matches_python_binding(gpu, gorio, tmp_path, pose
         if k % 2 == 0:
             g.setInputTarget(*frames[k])
             prev = np.eye(4, dtype=np.float32)
+
+
+PREINT_DRIVER = os.path.join(HOST, "test", "preint_sequence")
+
+
+def _imu_file(tmp_path, win):
+    path = os.path.join(tmp_path, "imu.bin")
+    with open(path, "wb") as f:
+        for t, d in ((win["gyr_t"], win["gyr"]), (win["vel_t"], win["vel"])):
+            f.write(struct.pack("i", len(t)))
+            f.write(np.concatenate([np.asarray(t)[:, None], d], axis=1).astype(np.float64).tobytes())
+        f.write(struct.pack("dd", win["start_t"], win["end_t"]))
+    return path
+
+
+def test_preint_driver_refuses_without_gpu(gorio, tmp_path):
+    subprocess.check_call(["make", "-C", HOST])
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([PREINT_DRIVER, _imu_file(str(tmp_path), synth.imu_window(seed=1))], capture_output=True, text=True)
+    assert r.returncode == 3 and "no usable HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_backend_call_sequence_ugpm(gpu, gorio, tmp_path):
+    """ugpm::VelPreintegration drop-in driven as radar_graph_slam_nodelet.cpp:465-530 does, against the ctypes binding."""
+    win = synth.imu_window(seed=11)
+    r = subprocess.run([PREINT_DRIVER, _imu_file(str(tmp_path), win)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    m = gorio.ugpm_preint_batch([win])[0][0]
+    assert np.allclose(np.array(lines[0]["delta_R"]).reshape(3, 3), m["delta_R"], rtol=0, atol=1e-15)
+    assert np.allclose(lines[0]["delta_p"], m["delta_p"], rtol=0, atol=1e-15)
+    assert lines[0]["dt"] == pytest.approx(1.0) and lines[0]["cov00"] == pytest.approx(m["cov"][0, 0], rel=1e-12)
+    mi = gorio.ugpm_preint_batch([win], vel_bias_std=0.3, gyr_bias_std=0.03)[0][0]
+    assert lines[1]["cov00_inflated"] == pytest.approx(mi["cov"][0, 0], rel=1e-12)  # host-side inflation == device-side inflation
