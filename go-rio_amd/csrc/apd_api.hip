@@ -14,6 +14,7 @@
 
 #include "../../include/gorio_apd.h"
 #include "apd_kernels.hip"
+#include "apd_index.hip"
 
 using namespace gorio;
 
@@ -33,7 +34,13 @@ struct DevCloud {
   int n = 0, n_pad = 0, cap = 0;
   bool present = false;
   int cov_count = 0;       // == source_covs_.size(): n when valid, 0 when stale
-  CloudView view() const { return CloudView{x, y, z, label, cov6, geo_w, n, n_pad}; }
+  // exact search accelerator (GORIO_SEARCH_PRUNED)
+  SearchIndex idx = SearchIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  unsigned long long* keys = nullptr;
+  unsigned int* bb = nullptr;
+  int idx_cap = 0, keys_cap = 0;
+  bool idx_valid = false;
+  CloudView view() const { return CloudView{x, y, z, label, cov6, geo_w, n, n_pad, idx}; }
 };
 
 }  // namespace
@@ -57,6 +64,8 @@ struct gorio_apd {
   PairState* d_states_batch = nullptr;
   KnnJob* d_jobs = nullptr;
   int jobs_cap = 0;
+  IndexJob* d_ijobs = nullptr;
+  int ijobs_cap = 0;
   double* d_fit = nullptr;
   std::string err;
   // profiling
@@ -84,6 +93,7 @@ int fail(gorio_apd* h, int code, const std::string& msg) {
 int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 void free_cloud(DevCloud& c) {
+  hipFree(c.idx.sx); hipFree(c.idx.sy); hipFree(c.idx.sz); hipFree(c.idx.orig); hipFree(c.idx.tbox); hipFree(c.idx.sbox); hipFree(c.keys); hipFree(c.bb);
   hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn); hipFree(c.part_d); hipFree(c.part_i);
   c = DevCloud();
 }
@@ -145,6 +155,7 @@ int upload_cloud(gorio_apd* h, DevCloud& c, const float* xyz, const float* label
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   c.present = true;
   c.cov_count = 0;
+  c.idx_valid = false;
   return GORIO_OK;
 }
 
@@ -169,6 +180,7 @@ int upload_cloud_device(gorio_apd* h, DevCloud& c, const float* dx, const float*
   HIP_TRY(h, hipGetLastError());
   c.present = true;
   c.cov_count = 0;
+  c.idx_valid = false;
   return GORIO_OK;
 }
 
@@ -223,12 +235,94 @@ void resolve_stage_events(gorio_apd* h) {
   h->ev_used = 0;
 }
 
+// Build the search accelerator of every listed cloud that lacks one (batched: one launch per sort stage for all clouds).
+int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*>>& clouds) {
+  std::vector<std::pair<gorio_apd*, DevCloud*>> todo;
+  for (auto& c : clouds)
+    if (!c.second->idx_valid) {
+      bool dup = false;
+      for (auto& t : todo) dup = dup || t.second == c.second;
+      if (!dup) todo.push_back(c);
+    }
+  if (todo.empty()) return GORIO_OK;
+  const int nj = (int)todo.size();
+  std::vector<IndexJob> jobs(nj);
+  std::vector<unsigned int> bbinit = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  int max_pow2 = kSortTile, max_spad = 512, max_n = 1;
+  for (int q = 0; q < nj; ++q) {
+    gorio_apd* h = todo[q].first;
+    DevCloud& c = *todo[q].second;
+    const int n_spad = roundup(c.n, 512);
+    int npow2 = kSortTile;
+    while (npow2 < c.n) npow2 <<= 1;
+    if (n_spad > c.idx_cap) {
+      hipFree(c.idx.sx); hipFree(c.idx.sy); hipFree(c.idx.sz); hipFree(c.idx.orig); hipFree(c.idx.tbox); hipFree(c.idx.sbox);
+      c.idx.sx = c.idx.sy = c.idx.sz = nullptr; c.idx.orig = nullptr; c.idx.tbox = c.idx.sbox = nullptr;
+      const int cap = n_spad + roundup(n_spad / 8, 512);
+      HIP_TRY(h, hipMalloc(&c.idx.sx, sizeof(float) * cap));
+      HIP_TRY(h, hipMalloc(&c.idx.sy, sizeof(float) * cap));
+      HIP_TRY(h, hipMalloc(&c.idx.sz, sizeof(float) * cap));
+      HIP_TRY(h, hipMalloc(&c.idx.orig, sizeof(int) * cap));
+      HIP_TRY(h, hipMalloc(&c.idx.tbox, sizeof(float) * 8 * (cap / 32)));
+      HIP_TRY(h, hipMalloc(&c.idx.sbox, sizeof(float) * 8 * (cap / 512)));
+      c.idx_cap = cap;
+    }
+    if (npow2 > c.keys_cap) {
+      hipFree(c.keys);
+      c.keys = nullptr;
+      HIP_TRY(h, hipMalloc(&c.keys, sizeof(unsigned long long) * npow2));
+      c.keys_cap = npow2;
+    }
+    if (!c.bb) HIP_TRY(h, hipMalloc(&c.bb, sizeof(unsigned int) * 6));
+    HIP_TRY(lead, hipMemcpyAsync(c.bb, bbinit.data(), sizeof(unsigned int) * 6, hipMemcpyHostToDevice, lead->stream));
+    c.idx.n = c.n;
+    c.idx.n_spad = n_spad;
+    c.idx.n_tiles = n_spad / 32;
+    c.idx.n_super = n_spad / 512;
+    IndexJob& j = jobs[q];
+    j.x = c.x; j.y = c.y; j.z = c.z; j.n = c.n; j.npow2 = npow2; j.keys = c.keys; j.bb = c.bb; j.idx = c.idx;
+    max_pow2 = std::max(max_pow2, npow2);
+    max_spad = std::max(max_spad, n_spad);
+    max_n = std::max(max_n, c.n);
+  }
+  if (nj > lead->ijobs_cap) {
+    hipFree(lead->d_ijobs);
+    lead->d_ijobs = nullptr;
+    HIP_TRY(lead, hipMalloc(&lead->d_ijobs, sizeof(IndexJob) * nj));
+    lead->ijobs_cap = nj;
+  }
+  HIP_TRY(lead, hipMemcpyAsync(lead->d_ijobs, jobs.data(), sizeof(IndexJob) * nj, hipMemcpyHostToDevice, lead->stream));
+  HIP_TRY(lead, hipStreamSynchronize(lead->stream));  // pageable staging
+  {
+    StageTimer t(lead, 0);
+    const IndexJob* dj = lead->d_ijobs;
+    bbox_kernel<<<dim3(std::min(64, (max_n + 255) / 256), nj), 256, 0, lead->stream>>>(dj);
+    morton_kernel<<<dim3((max_pow2 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
+    bitonic_tile_sort_kernel<<<dim3(max_pow2 / kSortTile, nj), 1024, 0, lead->stream>>>(dj);
+    for (int k = 2 * kSortTile; k <= max_pow2; k <<= 1) {
+      for (int j = k >> 1; j >= kSortTile; j >>= 1) bitonic_global_kernel<<<dim3((max_pow2 / 2 + 255) / 256, nj), 256, 0, lead->stream>>>(dj, k, j);
+      bitonic_tile_merge_kernel<<<dim3(max_pow2 / kSortTile, nj), 1024, 0, lead->stream>>>(dj, k);
+    }
+    gather_sorted_kernel<<<dim3((max_spad + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
+    box_tile_kernel<<<dim3((max_spad / 32 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
+    box_super_kernel<<<dim3((max_spad / 512 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
+  }
+  HIP_TRY(lead, hipGetLastError());
+  for (auto& t : todo) t.second->idx_valid = true;
+  return GORIO_OK;
+}
+
 // covariance estimation for a list of clouds on lead's stream
 int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*>>& todo) {
   if (todo.empty()) return GORIO_OK;
   const int njobs = (int)todo.size();
   const int k = lead->params.k_correspondences;
   const int K = k <= 20 ? 20 : 32;
+  const bool pruned = lead->params.search == GORIO_SEARCH_PRUNED;
+  if (pruned) {
+    int rc = run_index_build(lead, todo);
+    if (rc) return rc;
+  }
   long total_waves = 0;
   int max_n = 0;
   for (auto& t : todo) {
@@ -238,6 +332,7 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
   int splits = (int)((8192 + total_waves - 1) / total_waves);
   if (splits < 1) splits = 1;
   if (splits > 32) splits = 32;
+  if (pruned) splits = 1;
   std::vector<KnnJob> jobs(njobs);
   int max_splits = 1;
   for (int q = 0; q < njobs; ++q) {
@@ -245,7 +340,7 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     DevCloud& c = *todo[q].second;
     int chunk = roundup((c.n_pad + splits - 1) / splits, kPad);
     if (chunk < 256) chunk = 256;
-    const int s = (c.n_pad + chunk - 1) / chunk;
+    const int s = pruned ? 1 : (c.n_pad + chunk - 1) / chunk;
     if (s > max_splits) max_splits = s;
     const size_t need = (size_t)s * K * c.n;
     if (need > c.part_cap) {
@@ -282,17 +377,37 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
   {
     StageTimer t(lead, 0);
     dim3 g1((max_n + 255) / 256, max_splits, njobs), g2((max_n + 255) / 256, 1, njobs);
+    dim3 gp((roundup(max_n, 512) + 255) / 256, 1, njobs);
     if (K == 20) {
-      knn_partial_kernel<20><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
+      if (pruned) knn_pruned_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
+      else knn_partial_kernel<20><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
       cov_finalize_kernel<20><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
     } else {
-      knn_partial_kernel<32><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
+      if (pruned) knn_pruned_kernel<32><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
+      else knn_partial_kernel<32><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
       cov_finalize_kernel<32><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
     }
   }
   HIP_TRY(lead, hipGetLastError());
   for (auto& t : todo) t.second->cov_count = t.second->n;
   return GORIO_OK;
+}
+
+// largest float f with (double)f < thr2: candidates beyond it can never pass the gate of APD:183
+float gate_bound(double thr2) {
+  if (!(thr2 < (double)FLT_MAX)) return FLT_MAX;
+  float f = (float)thr2;
+  while (!((double)f < thr2)) f = std::nextafterf(f, 0.0f);
+  return f;
+}
+
+void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_spad, int count) {
+  if (lead->params.search == GORIO_SEARCH_PRUNED) {
+    const double thr = lead->params.corr_dist_threshold;
+    nn_search_pruned_kernel<<<dim3((max_src_spad + 255) / 256, 1, count), 256, 0, lead->stream>>>(d_desc, gate_bound(thr * thr));
+  } else {
+    nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(d_desc);
+  }
 }
 
 int check_ready(gorio_apd* h) {
@@ -376,6 +491,15 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
   int rc = run_covariances(lead, todo);
   if (rc) return rc;
 
+  if (lead->params.search == GORIO_SEARCH_PRUNED) {
+    std::vector<std::pair<gorio_apd*, DevCloud*>> all;
+    for (int q = 0; q < count; ++q) {
+      all.emplace_back(hs[q], &hs[q]->src);
+      all.emplace_back(hs[q], &hs[q]->tgt);
+    }
+    rc = run_index_build(lead, all);
+    if (rc) return rc;
+  }
   rc = ensure_batch(lead, count);
   if (rc) return rc;
   long total_src_waves = 0;
@@ -409,11 +533,11 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     const int todo_it = std::min(chunk_iters, max_it - launched);
     for (int it = 0; it < todo_it; ++it) {
       if (lead->profiling) {
-        { StageTimer t(lead, 1); nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(lead->d_desc); }
+        { StageTimer t(lead, 1); launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), count); }
         { StageTimer t(lead, 2); linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst); }
         { StageTimer t(lead, 3); lm_solve_kernel<<<g_lm, 1024, 0, lead->stream>>>(lead->d_desc, cst, 0); }
       } else {
-        nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(lead->d_desc);
+        launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), count);
         linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst);
         lm_solve_kernel<<<g_lm, 1024, 0, lead->stream>>>(lead->d_desc, cst, 0);
       }
@@ -503,7 +627,7 @@ void gorio_apd_destroy(gorio_apd_t* h) {
   free_cloud(h->src);
   free_cloud(h->tgt);
   hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
-  hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_fit);
+  hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_ijobs); hipFree(h->d_fit);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -654,6 +778,11 @@ int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b
   if (rc) return rc;
   rc = gorio_apd_calculate_covariances(h);
   if (rc) return rc;
+  if (h->params.search == GORIO_SEARCH_PRUNED) {
+    std::vector<std::pair<gorio_apd*, DevCloud*>> all = {{h, &h->src}, {h, &h->tgt}};
+    rc = run_index_build(h, all);
+    if (rc) return rc;
+  }
   rc = single_desc(h);
   if (rc) return rc;
   PairState s;
@@ -664,7 +793,7 @@ int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b
   PairDesc d;
   fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
   const int nbx = (h->src.n + 255) / 256;
-  nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
+  launch_nn(h, h->d_desc, dim3(nbx, d.nn_splits, 1), roundup(h->src.n, 512), 1);
   linearize_kernel<<<dim3(nbx, 1, 1), 256, 0, h->stream>>>(h->d_desc, cst);
   lm_solve_kernel<<<1, 1024, 0, h->stream>>>(h->d_desc, cst, 1);
   HIP_TRY(h, hipGetLastError());

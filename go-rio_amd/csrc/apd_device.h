@@ -13,6 +13,23 @@
 
 namespace gorio {
 
+// Exact search accelerator of one cloud (the role pcl::search::KdTree plays in the reference, APDH:106-107): a Morton-ordered COPY
+// of the coordinates with the original index of every point, axis-aligned boxes of 32-point tiles and of 16-tile super tiles.
+// Searches visit tiles in an order that finds near candidates first and skip every tile whose box is farther than the current
+// bound, so they return exactly what the exhaustive search returns (ties included: candidates compare as (distance, original index)).
+struct SearchIndex {
+  float* sx;     // [n_spad] Morton-ordered coordinates, padded with 1e30
+  float* sy;
+  float* sz;
+  int* orig;     // [n_spad] original index, 0x7fffffff for padding
+  float* tbox;   // [n_tiles][8]  lo.x lo.y lo.z - hi.x hi.y hi.z -   (tile = 32 consecutive sorted points; empty: lo = +inf, hi = -inf)
+  float* sbox;   // [n_super][8]  (super tile = 16 tiles = 512 points)
+  int n;
+  int n_spad;    // multiple of 512
+  int n_tiles;
+  int n_super;
+};
+
 struct CloudView {
   float* x;
   float* y;
@@ -22,6 +39,7 @@ struct CloudView {
   double* geo_w;
   int n;
   int n_pad;
+  SearchIndex idx;  // valid only in GORIO_SEARCH_PRUNED mode
 };
 
 // device-resident optimiser state of one scan pair (the members of LsqRegistration, LSQH:75-84, plus loop bookkeeping)
@@ -84,6 +102,18 @@ struct ApdConsts {
   int lm_max_iterations;
   int max_iterations;
   int pad_;
+};
+
+// one cloud whose search index is being built (batched over blockIdx.y)
+struct IndexJob {
+  const float* x;
+  const float* y;
+  const float* z;
+  int n;
+  int npow2;                  // sort size (power of two >= n, >= 4096)
+  unsigned long long* keys;   // [npow2] (33-bit Morton code) << 31 | index
+  unsigned int* bb;           // [6] order-preserving encodings of min x,y,z / max x,y,z
+  SearchIndex idx;
 };
 
 struct TfArg {

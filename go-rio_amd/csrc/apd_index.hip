@@ -1,0 +1,390 @@
+// apd_index.hip -- building the exact search accelerator (SearchIndex, apd_device.h) and the two branch-and-bound searches that
+// use it.  Included by apd_api.hip after apd_kernels.hip.
+//
+//   bbox_kernel / morton_kernel      bounding box, 3 x 11-bit Morton code per point
+//   bitonic_*_kernel                 LDS-tiled bitonic sort of (code << 31 | index) keys
+//   gather_sorted_kernel / box_kernel   Morton-ordered copy + tile / super-tile boxes
+//   nn_search_pruned_kernel          1-NN correspondences (APD:164-180), same packed-key output as nn_search_kernel
+//   knn_pruned_kernel                self k-NN (APD:364), same list layout as knn_partial_kernel with splits = 1
+//
+// Why the pruning is exact: the lower bound of a box is evaluated with the SAME float expression as a point distance
+// (dx*dx, + dy*dy, + dz*dz on the clamped coordinate differences).  Every IEEE operation in it is monotone in |dx|, |dy|, |dz|,
+// and a point inside the box has component differences at least as large as the clamped ones, so bound <= distance holds in
+// float arithmetic, not just in exact arithmetic.  A tile is skipped only when bound > current best, hence no skipped point can
+// beat or tie the final answer; ties are broken on the ORIGINAL index, so the result equals the exhaustive search bit for bit.
+#include <hip/hip_runtime.h>
+
+namespace gorio {
+
+__device__ __forceinline__ unsigned int f2ord(float f) {  // order-preserving float -> uint
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned int o) {
+  const unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+// grid: (blocks, jobs), block 256
+__global__ __launch_bounds__(256) void bbox_kernel(const IndexJob* __restrict__ jobs) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.n; i += gridDim.x * 256) {
+    const float v[3] = {jb.x[i], jb.y[i], jb.z[i]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fminf(lo[a], v[a]);
+      hi[a] = fmaxf(hi[a], v[a]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(jb.bb + a, f2ord(lo[a]));
+      atomicMax(jb.bb + 3 + a, f2ord(hi[a]));
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long spread11(unsigned int v) {  // 11 bits -> every third bit
+  unsigned long long x = v & 0x7ffu;
+  x = (x | (x << 32)) & 0x1f00000000ffffull;
+  x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+  x = (x | (x << 8)) & 0x100f00f00f00f00full;
+  x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+
+// grid: (blocks over npow2, jobs)
+__global__ __launch_bounds__(256) void morton_kernel(const IndexJob* __restrict__ jobs) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= jb.npow2) return;
+  unsigned long long key = ~0ull;
+  if (i < jb.n) {
+    unsigned int q[3];
+    const float v[3] = {jb.x[i], jb.y[i], jb.z[i]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float lo = ord2f(jb.bb[a]), hi = ord2f(jb.bb[3 + a]);
+      const float ext = fmaxf(hi - lo, 1e-6f);
+      float t = (v[a] - lo) / ext * 2047.0f;
+      t = fminf(fmaxf(t, 0.0f), 2047.0f);
+      q[a] = (unsigned int)t;
+    }
+    const unsigned long long code = spread11(q[0]) | (spread11(q[1]) << 1) | (spread11(q[2]) << 2);
+    key = (code << 31) | (unsigned long long)i;
+  }
+  jb.keys[i] = key;
+}
+
+constexpr int kSortTile = 4096;  // u64 keys per LDS tile (32 KB), 1024 threads
+
+__device__ __forceinline__ void cmpx(unsigned long long& a, unsigned long long& b, bool up) {
+  if ((a > b) == up) {
+    const unsigned long long t = a;
+    a = b;
+    b = t;
+  }
+}
+
+// full bitonic sort of every 4096-key tile in LDS; direction alternates with the tile index so that tiles pair into bitonic
+// sequences for the global stages.  grid: (max tiles, jobs), block 1024
+__global__ __launch_bounds__(1024) void bitonic_tile_sort_kernel(const IndexJob* __restrict__ jobs) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  const int base = blockIdx.x * kSortTile;
+  if (base >= jb.npow2) return;
+  __shared__ unsigned long long s[kSortTile];
+  for (int q = threadIdx.x; q < kSortTile; q += 1024) s[q] = jb.keys[base + q];
+  __syncthreads();
+  for (int k = 2; k <= kSortTile; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < kSortTile / 2; t += 1024) {
+        const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+        const bool up = (((base + lo) & k) == 0);
+        unsigned long long a = s[lo], b = s[hi];
+        cmpx(a, b, up);
+        s[lo] = a;
+        s[hi] = b;
+      }
+      __syncthreads();
+    }
+  }
+  for (int q = threadIdx.x; q < kSortTile; q += 1024) jb.keys[base + q] = s[q];
+}
+
+// one global compare-exchange stage (stride j >= kSortTile) of merge size k.  grid: (max npow2 / 2 / 256, jobs), block 256
+__global__ __launch_bounds__(256) void bitonic_global_kernel(const IndexJob* __restrict__ jobs, int k, int j) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  if (k > jb.npow2) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= jb.npow2 / 2) return;
+  const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+  const bool up = ((lo & k) == 0);
+  unsigned long long a = jb.keys[lo], b = jb.keys[hi];
+  if ((a > b) == up) {
+    jb.keys[lo] = b;
+    jb.keys[hi] = a;
+  }
+}
+
+// remaining stages (stride < kSortTile) of merge size k inside LDS.  grid: (max tiles, jobs), block 1024
+__global__ __launch_bounds__(1024) void bitonic_tile_merge_kernel(const IndexJob* __restrict__ jobs, int k) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  if (k > jb.npow2) return;
+  const int base = blockIdx.x * kSortTile;
+  if (base >= jb.npow2) return;
+  __shared__ unsigned long long s[kSortTile];
+  for (int q = threadIdx.x; q < kSortTile; q += 1024) s[q] = jb.keys[base + q];
+  __syncthreads();
+  for (int j = kSortTile >> 1; j > 0; j >>= 1) {
+    for (int t = threadIdx.x; t < kSortTile / 2; t += 1024) {
+      const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+      const bool up = (((base + lo) & k) == 0);
+      unsigned long long a = s[lo], b = s[hi];
+      cmpx(a, b, up);
+      s[lo] = a;
+      s[hi] = b;
+    }
+    __syncthreads();
+  }
+  for (int q = threadIdx.x; q < kSortTile; q += 1024) jb.keys[base + q] = s[q];
+}
+
+// grid: (blocks over n_spad, jobs)
+__global__ __launch_bounds__(256) void gather_sorted_kernel(const IndexJob* __restrict__ jobs) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= jb.idx.n_spad) return;
+  if (p < jb.n) {
+    const int i = (int)(jb.keys[p] & 0x7fffffffull);
+    jb.idx.sx[p] = jb.x[i];
+    jb.idx.sy[p] = jb.y[i];
+    jb.idx.sz[p] = jb.z[i];
+    jb.idx.orig[p] = i;
+  } else {
+    jb.idx.sx[p] = 1e30f;
+    jb.idx.sy[p] = 1e30f;
+    jb.idx.sz[p] = 1e30f;
+    jb.idx.orig[p] = 0x7fffffff;
+  }
+}
+
+// boxes of 32-point tiles (one thread per tile) -- grid: (blocks over n_tiles, jobs); then super tiles in box_super_kernel
+__global__ __launch_bounds__(256) void box_tile_kernel(const IndexJob* __restrict__ jobs) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= jb.idx.n_tiles) return;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int q = 0; q < 32; ++q) {
+    const int p = t * 32 + q;
+    if (p < jb.n) {
+      const float v[3] = {jb.idx.sx[p], jb.idx.sy[p], jb.idx.sz[p]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = fminf(lo[a], v[a]);
+        hi[a] = fmaxf(hi[a], v[a]);
+      }
+    }
+  }
+  float* b = jb.idx.tbox + (size_t)t * 8;
+  b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = 0.f;
+  b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = 0.f;
+}
+__global__ __launch_bounds__(256) void box_super_kernel(const IndexJob* __restrict__ jobs) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= jb.idx.n_super) return;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int q = 0; q < 16; ++q) {
+    const int t = s * 16 + q;
+    if (t < jb.idx.n_tiles) {
+      const float* b = jb.idx.tbox + (size_t)t * 8;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = fminf(lo[a], b[a]);
+        hi[a] = fmaxf(hi[a], b[4 + a]);
+      }
+    }
+  }
+  float* b = jb.idx.sbox + (size_t)s * 8;
+  b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = 0.f;
+  b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = 0.f;
+}
+
+// ----------------------------------------------------------------------------------------------- branch-and-bound searches
+
+// float lower bound of sqdist3(q, p) over all p in the box; same operation sequence as sqdist3 (see the header comment)
+__device__ __forceinline__ float box_bound(float qx, float qy, float qz, const float* __restrict__ b) {
+  const float cx = fminf(fmaxf(qx, b[0]), b[4]);
+  const float cy = fminf(fmaxf(qy, b[1]), b[5]);
+  const float cz = fminf(fmaxf(qz, b[2]), b[6]);
+  const float dx = qx - cx, dy = qy - cy, dz = qz - cz;
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+typedef const int __attribute__((address_space(4)))* scalar_ip;
+
+// 1-NN of every source point in the target, pruned.  One lane = one source point taken in MORTON order (a wave's 64 queries are
+// spatially compact, so they agree on which tiles matter).  grid: (ceil(n_spad_src / 256), 1, pairs), block 256.
+// Output: best_key[orig source index] = (float bits of d) << 32 | orig target index, exactly as nn_search_kernel.
+__global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* __restrict__ descs, float bound_f) {
+  const PairDesc& pd = descs[blockIdx.z];
+  const PairState* __restrict__ st = pd.state;
+  if (st->done) return;
+  const SearchIndex& si = pd.src.idx;
+  const SearchIndex& ti = pd.tgt.idx;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= si.n) return;
+  const int pq = p < si.n ? p : si.n - 1;
+  float qx, qy, qz;
+  transform_f(st->Tf, si.sx[pq], si.sy[pq], si.sz[pq], qx, qy, qz);
+  const scalar_fp tx = as_scalar(ti.sx);
+  const scalar_fp ty = as_scalar(ti.sy);
+  const scalar_fp tz = as_scalar(ti.sz);
+  const scalar_ip to = (scalar_ip)ti.orig;
+  const scalar_fp tb = as_scalar(ti.tbox);
+  const scalar_fp sb = as_scalar(ti.sbox);
+  // candidates farther than the correspondence gate can never be accepted (APD:183): start from the gate as the bound
+  unsigned long long best = ((unsigned long long)__float_as_uint(bound_f) << 32) | 0xffffffffull;
+  float bestd = bound_f;
+  // visit super tiles outward from the one at the same relative Morton position
+  const int ns = ti.n_super;
+  const int wave_first = (blockIdx.x * 256 + (threadIdx.x & ~63));
+  int s0 = (int)(((long)wave_first * ns) / (si.n > 0 ? si.n : 1));
+  s0 = __builtin_amdgcn_readfirstlane(s0 < ns ? s0 : ns - 1);
+  for (int v = 0; v < 2 * ns; ++v) {
+    const int off = (v + 1) >> 1;
+    const int s = (v & 1) ? s0 - off : s0 + off;
+    if (s < 0 || s >= ns) continue;
+    float sbv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sbv[q] = sb[s * 8 + q];
+    if (__ballot(box_bound(qx, qy, qz, sbv) <= bestd) == 0) continue;
+    const int t1 = min(s * 16 + 16, ti.n_tiles);
+    for (int t = s * 16; t < t1; ++t) {
+      float tbv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tbv[q] = tb[t * 8 + q];
+      if (__ballot(box_bound(qx, qy, qz, tbv) <= bestd) == 0) continue;
+      const int j0 = t * 32;
+#pragma unroll
+      for (int g = 0; g < 32; g += 8) {
+        float d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + g + u], ty[j0 + g + u], tz[j0 + g + u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const unsigned long long key = ((unsigned long long)__float_as_uint(d[u]) << 32) | (unsigned int)to[j0 + g + u];
+          best = key < best ? key : best;
+        }
+      }
+      bestd = __uint_as_float((unsigned int)(best >> 32));
+    }
+  }
+  if (p < si.n && (unsigned int)best != 0xffffffffu) pd.best_key[si.orig[p]] = best;
+}
+
+// lexicographic (distance, original index) insertion into an ascending register list
+template <int K>
+__device__ __forceinline__ void topk_insert_lex(float (&bd)[K], int (&bi)[K], float cd, int ci) {
+  bool ins = false;
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    ins = ins || (cd < bd[t]) || (cd == bd[t] && ci < bi[t]);
+    const float td = bd[t];
+    const int tin = bi[t];
+    bd[t] = ins ? cd : td;
+    bi[t] = ins ? ci : tin;
+    cd = ins ? td : cd;
+    ci = ins ? tin : ci;
+  }
+}
+
+// self k-NN, pruned.  Writes the final sorted list of every point to part_d / part_i in the [split = 0][t][orig index] layout that
+// cov_finalize_kernel reads.  grid: (ceil(n_spad / 256), 1, clouds), block 256.
+template <int K>
+__global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restrict__ jobs) {
+  const KnnJob& job = jobs[blockIdx.z];
+  const SearchIndex& si = job.cloud.idx;
+  const int n = si.n;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= n) return;
+  const int pq = p < n ? p : n - 1;
+  const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
+  const scalar_fp tx = as_scalar(si.sx);
+  const scalar_fp ty = as_scalar(si.sy);
+  const scalar_fp tz = as_scalar(si.sz);
+  const scalar_ip to = (scalar_ip)si.orig;
+  const scalar_fp tb = as_scalar(si.tbox);
+  const scalar_fp sb = as_scalar(si.sbox);
+  float bd[K];
+  int bi[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    bd[t] = INFINITY;
+    bi[t] = 0x7fffffff;
+  }
+  const int ns = si.n_super;
+  const int s0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + (threadIdx.x & ~63)) / 512);
+  for (int v = 0; v < 2 * ns; ++v) {
+    const int off = (v + 1) >> 1;
+    const int s = (v & 1) ? s0 - off : s0 + off;
+    if (s < 0 || s >= ns) continue;
+    float sbv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sbv[q] = sb[s * 8 + q];
+    if (__ballot(box_bound(qx, qy, qz, sbv) <= bd[K - 1]) == 0) continue;
+    // within the own super tile start at the own tile and walk outward, elsewhere in order
+    const int tbase = s * 16;
+    const int own = (s == s0) ? (__builtin_amdgcn_readfirstlane(blockIdx.x * 256 + (threadIdx.x & ~63)) / 32) - tbase : 0;
+    for (int w = 0; w < 32; ++w) {
+      int t;
+      if (s == s0) {
+        const int o2 = (w + 1) >> 1;
+        t = (w & 1) ? own - o2 : own + o2;
+        if (t < 0 || t >= 16) continue;
+      } else {
+        if (w >= 16) break;
+        t = w;
+      }
+      t += tbase;
+      if (t >= si.n_tiles) continue;
+      float tbv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tbv[q] = tb[t * 8 + q];
+      if (__ballot(box_bound(qx, qy, qz, tbv) <= bd[K - 1]) == 0) continue;
+      const int j0 = t * 32;
+#pragma unroll
+      for (int g = 0; g < 32; g += 8) {
+        float d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + g + u], ty[j0 + g + u], tz[j0 + g + u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int oi = to[j0 + g + u];
+          if (d[u] < bd[K - 1] || (d[u] == bd[K - 1] && oi < bi[K - 1])) topk_insert_lex<K>(bd, bi, d[u], oi);
+        }
+      }
+    }
+  }
+  if (p < n) {
+    const size_t base = (size_t)si.orig[p];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      job.part_d[base + (size_t)t * n] = bd[t];
+      job.part_i[base + (size_t)t * n] = bi[t];
+    }
+  }
+}
+
+}  // namespace gorio

@@ -299,3 +299,84 @@ def test_16k_properties(gpu, gorio, pose_err):
     r = g2.align()
     te, re = pose_err(T, r["T"])
     assert r["converged"] and te < 1e-4 and re < 1e-4, (te, re)
+
+
+# ---------------------------------------------------------------------------------------------- exact pruned search
+
+@pytest.mark.parametrize("n,m", [(20, 33), (500, 700), (2000, 2300), (5000, 4097)])
+def test_pruned_search_equals_brute_force_and_oracle(gpu, gorio, oracle_apd, n, m):
+    """GORIO_SEARCH_PRUNED returns the same correspondences (bit-exact, ties included), k-NN lists, covariances, H and b."""
+    sx, sl, tx, tl, _ = synth.scan_pair(n, m, seed=70 + n)
+    T = _pose()
+    gb = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, search=0)
+    gp = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, search=1)
+    eb, Hb, bb = gb.linearize(T)
+    ep, Hp, bp = gp.linearize(T)
+    cb, sb = gb.getCorrespondences()
+    cp, sp = gp.getCorrespondences()
+    assert np.array_equal(cb, cp)
+    assert np.array_equal(sb[cb >= 0], sp[cp >= 0]) and np.all(np.isinf(sp[cp < 0]))  # rejected points: distance not searched for
+    assert np.array_equal(gb.getKnnIndices(0), gp.getKnnIndices(0)) and np.array_equal(gb.getKnnIndices(1), gp.getKnnIndices(1))
+    assert np.array_equal(gb.getSourceCovariances(), gp.getSourceCovariances())
+    assert rel(Hp, Hb) < 1e-13 and rel(bp, bb) < 1e-12 and abs(ep - eb) <= 1e-13 * abs(eb)
+    idx_o, _ = oracle_apd.knn_self(sx, 20)
+    assert np.array_equal(gp.getKnnIndices(0), idx_o)
+
+
+def test_pruned_search_ties_and_duplicates(gpu, gorio, oracle_apd):
+    gx, gy = np.meshgrid(np.arange(20, dtype=np.float32), np.arange(20, dtype=np.float32))
+    lattice = np.stack([gx.ravel(), gy.ravel(), np.zeros(400, np.float32)], axis=1)
+    xyz = np.concatenate([lattice, lattice[:100]])  # exact duplicates + a lattice full of equal distances
+    g = make(gorio, xyz, None, xyz, None, regularization=0, search=1, corr_dist_threshold=2.0)
+    g.calculateCovariances()
+    idx_o, _ = oracle_apd.knn_self(xyz, 20)
+    assert np.array_equal(g.getKnnIndices(0), idx_o)
+    shifted = lattice + np.float32(0.5)  # every query is equidistant from 4 lattice points
+    g2 = make(gorio, shifted, None, xyz, None, search=1, corr_dist_threshold=2.0)
+    g2.linearize(np.eye(4))
+    corr, _ = g2.getCorrespondences()
+    p = oracle_apd.launch_params()
+    z = np.zeros((500, 4, 4))
+    corr_o, _, _ = oracle_apd.update_correspondences(np.eye(4), shifted, xyz, np.zeros((400, 4, 4)), z, p)
+    assert np.array_equal(corr, corr_o)
+
+
+def test_pruned_search_default_threshold(gpu, gorio):
+    """corr_dist_threshold_ = FLT_MAX (APD:23): nothing is gated, the bound comes from the search itself."""
+    sx, sl, tx, tl, _ = synth.scan_pair(1500, 1700, seed=3)
+    gb = make(gorio, sx, sl, tx, tl, search=0)
+    gp = make(gorio, sx, sl, tx, tl, search=1)
+    gb.linearize(np.eye(4))
+    gp.linearize(np.eye(4))
+    cb, sb = gb.getCorrespondences()
+    cp, sp = gp.getCorrespondences()
+    assert np.array_equal(cb, cp) and np.array_equal(sb, sp) and np.all(cp >= 0)
+
+
+def test_pruned_align_identical_to_brute_force(gpu, gorio):
+    sx, sl, tx, tl, _ = synth.scan_pair(5000, 5000, seed=20250704)
+    rb = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, transformation_epsilon=0.1, search=0).align()
+    rp = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, transformation_epsilon=0.1, search=1).align()
+    assert rb["n_linearize"] == rp["n_linearize"] and rb["converged"] == rp["converged"]
+    assert np.allclose(rb["T"], rp["T"], rtol=0, atol=1e-6)
+    pairs = [synth.scan_pair(900 + 37 * q, 1000 + 91 * q, seed=40 + q) for q in range(4)]
+    ob = [make(gorio, *pr[:4], corr_dist_threshold=2.0, transformation_epsilon=0.05, search=0) for pr in pairs]
+    op = [make(gorio, *pr[:4], corr_dist_threshold=2.0, transformation_epsilon=0.05, search=1) for pr in pairs]
+    for a, b in zip(gorio.align_batch(ob), gorio.align_batch(op)):
+        assert a["n_linearize"] == b["n_linearize"] and np.allclose(a["T"], b["T"], rtol=0, atol=1e-6)
+
+
+def test_pruned_16k_and_map(gpu, gorio):
+    """BASELINE sizes: 16k x 16k and 16k x 100k (C3): pruned == brute force on every correspondence."""
+    sx, sl = synth.radar_scan(16384, seed=5)
+    tx, tl = synth.local_map(100000, seed=6)
+    T = synth.gt_transform([0.1, 0.05, 0.0], [0.0, 0.0, 0.5])
+    gb = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, search=0)
+    gp = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, search=1)
+    eb, Hb, bb = gb.linearize(T)
+    ep, Hp, bp = gp.linearize(T)
+    cb, _ = gb.getCorrespondences()
+    cp, _ = gp.getCorrespondences()
+    assert np.array_equal(cb, cp) and (cb >= 0).sum() > 8000
+    assert rel(Hp, Hb) < 1e-12
+    assert np.array_equal(gb.getKnnIndices(1), gp.getKnnIndices(1))
