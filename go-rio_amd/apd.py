@@ -37,6 +37,7 @@ class ApdParams(C.Structure):
         ("lm_max_iterations", C.c_int),
         ("lm_init_lambda_factor", C.c_double),
         ("search", C.c_int),
+        ("cl_weight_points", C.c_int),
     ]
 
 

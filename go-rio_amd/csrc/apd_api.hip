@@ -184,7 +184,7 @@ int upload_cloud_device(gorio_apd* h, DevCloud& c, const float* dx, const float*
   return GORIO_OK;
 }
 
-ApdConsts make_consts(const gorio_apd_params& p) {
+ApdConsts make_consts(const gorio_apd_params& p) {  // inv_n_scale is patched per launch set by cl_scale()
   ApdConsts c;
   c.thr2 = p.corr_dist_threshold * p.corr_dist_threshold;
   c.dist_var = p.dist_var;
@@ -438,7 +438,7 @@ void fill_desc(gorio_apd* h, PairDesc& d, PairState* state, long total_src_waves
   if (chunk < 512) chunk = 512;
   d.nn_chunk = chunk;
   d.nn_splits = (h->tgt.n_pad + chunk - 1) / chunk;
-  d.pad_ = 0;
+  d.cl_points = h->params.cl_weight_points;
 }
 
 void init_state(PairState& s, const double* T16) {
@@ -598,6 +598,7 @@ void gorio_apd_default_params(gorio_apd_params* p) {
   p->lm_max_iterations = 10;
   p->lm_init_lambda_factor = 1e-9;
   p->search = GORIO_SEARCH_BRUTE_FORCE;
+  p->cl_weight_points = 0;
 }
 
 int gorio_apd_create(gorio_apd_t** out, int device) {

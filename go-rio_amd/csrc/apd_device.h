@@ -75,7 +75,7 @@ struct PairDesc {
   int nblk;          // ceil(src.n / 256)
   int nn_splits;     // target range split count for nn_search_kernel
   int nn_chunk;      // candidates per split (multiple of 16)
-  int pad_;
+  int cl_points;     // N of cl_weight = 1/N (APD:273); 0 = src.n
 };
 
 struct KnnJob {

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(const PairDesc* __restri
       om[0] = p.o00; om[1] = p.o01; om[2] = p.o02; om[3] = p.o11; om[4] = p.o12; om[5] = p.o22;
 
       const double quad = residual_terms(T, ax, ay, az, pd.tgt.x[j], pd.tgt.y[j], pd.tgt.z[j], p);  // APD:255-263
-      const double w = 1.0 + pd.src.geo_w[i] + ((pd.tgt.label[j] == pd.src.label[i]) ? cst.inv_n_scale / (double)n : 0.0);  // APD:266-276
+      const double w = 1.0 + pd.src.geo_w[i] + ((pd.tgt.label[j] == pd.src.label[i]) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);  // APD:266-276
       acc[27] = w * quad;
 
       // J = [skew(Ta) | -I], APD:284-287.  With S = skew(Ta): H_rr = S^T O S, H_rt = -S^T O, H_tt = O, b_r = S^T O e, b_t = -O e.
@@ -614,7 +614,7 @@ __device__ double block_error(const PairDesc& pd, const double* __restrict__ T, 
     PointTerms p;
     p.o00 = om[0]; p.o01 = om[1]; p.o02 = om[2]; p.o11 = om[3]; p.o12 = om[4]; p.o22 = om[5];
     const double quad = residual_terms(T, pd.src.x[i], pd.src.y[i], pd.src.z[i], pd.tgt.x[j], pd.tgt.y[j], pd.tgt.z[j], p);
-    const double w = 1.0 + pd.src.geo_w[i] + ((pd.tgt.label[j] == pd.src.label[i]) ? cst.inv_n_scale / (double)n : 0.0);
+    const double w = 1.0 + pd.src.geo_w[i] + ((pd.tgt.label[j] == pd.src.label[i]) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);
     sum += w * quad;
   }
   sum = wave_sum(sum);

@@ -57,6 +57,8 @@ typedef struct {
   int lm_max_iterations;         /* default 10 (LSQ:19) */
   double lm_init_lambda_factor;  /* setInitialLambdaFactor LSQ:35; default 1e-9 (LSQ:20) */
   int search;                    /* gorio_search; default brute force */
+  int cl_weight_points;          /* N in cl_weight = 1/N (APD:273: correspondences_.size()); 0 = this handle's source size.  Set it to
+                                    the global source size when the source cloud is sharded over several handles / GPUs */
 } gorio_apd_params;
 
 typedef struct gorio_apd gorio_apd_t;
