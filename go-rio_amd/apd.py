@@ -70,7 +70,8 @@ def load_library():
 
 
 def _p(a, t):
-    return a.ctypes.data_as(C.POINTER(t))
+    """Typed pointer to a contiguous array without going through ndarray.ctypes (slow once torch is imported)."""
+    return C.cast(a.__array_interface__["data"][0], C.POINTER(t))
 
 
 def _check(h, rc):

@@ -8,7 +8,9 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -78,6 +80,33 @@ struct gorio_apd {
 };
 
 namespace {
+
+// All handles of one device share ONE launch stream: setInput* copies, index builds and align batches of different handles are
+// then ordered by the stream itself and a batch needs no cross-stream synchronisation.  (UGPM uses its own stream and overlaps.)
+hipStream_t device_stream(int device) {
+  static std::mutex mu;
+  static std::vector<hipStream_t> streams;
+  std::lock_guard<std::mutex> lock(mu);
+  if ((int)streams.size() <= device) streams.resize(device + 1, nullptr);
+  if (!streams[device]) {
+    // GORIO_CU_SPLIT=k (1..7): reserve k/8 of the CUs for the UGPM stream and keep this stream off them, so that scan matching and
+    // GP pre-integration running side by side do not queue behind each other's workgroups (hipExtStreamCreateWithCUMask).
+    const char* split = std::getenv("GORIO_CU_SPLIT");
+    const int k = split ? std::atoi(split) : 0;
+    bool made = false;
+    if (k >= 1 && k <= 7) {
+      uint32_t mask[8];
+      for (int w = 0; w < 8; ++w) {
+        mask[w] = 0;
+        for (int b = 0; b < 32; ++b)
+          if (((w * 32 + b) % 8) >= k) mask[w] |= (1u << b);
+      }
+      made = hipExtStreamCreateWithCUMask(&streams[device], 8, mask) == hipSuccess;
+    }
+    if (!made && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) return nullptr;
+  }
+  return streams[device];
+}
 
 int fail(gorio_apd* h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -159,11 +188,21 @@ int upload_cloud(gorio_apd* h, DevCloud& c, const float* xyz, const float* label
   return GORIO_OK;
 }
 
-__global__ void fill_pad_kernel(float* x, float* y, float* z, float* label, int n, int n_pad, int has_label) {
+// setInput* from device-resident SoA buffers: one launch copies the four arrays and writes the padding
+__global__ __launch_bounds__(256) void copy_cloud_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const float* __restrict__ sl,
+                                                         float* __restrict__ x, float* __restrict__ y, float* __restrict__ z, float* __restrict__ label, int n, int n_pad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_pad) {
-    if (i >= n) { x[i] = 1e30f; y[i] = 1e30f; z[i] = 1e30f; label[i] = 0.0f; }
-    else if (!has_label) label[i] = 0.0f;
+  if (i >= n_pad) return;
+  if (i < n) {
+    x[i] = sx[i];
+    y[i] = sy[i];
+    z[i] = sz[i];
+    label[i] = sl ? sl[i] : 0.0f;
+  } else {
+    x[i] = 1e30f;
+    y[i] = 1e30f;
+    z[i] = 1e30f;
+    label[i] = 0.0f;
   }
 }
 
@@ -172,11 +211,7 @@ int upload_cloud_device(gorio_apd* h, DevCloud& c, const float* dx, const float*
   HIP_TRY(h, hipSetDevice(h->device));
   int rc = ensure_cloud(h, c, n);
   if (rc) return rc;
-  HIP_TRY(h, hipMemcpyAsync(c.x, dx, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(c.y, dy, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(c.z, dz, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
-  if (dl) HIP_TRY(h, hipMemcpyAsync(c.label, dl, sizeof(float) * n, hipMemcpyDeviceToDevice, h->stream));
-  fill_pad_kernel<<<(c.n_pad + 255) / 256, 256, 0, h->stream>>>(c.x, c.y, c.z, c.label, n, c.n_pad, dl ? 1 : 0);
+  copy_cloud_kernel<<<(c.n_pad + 255) / 256, 256, 0, h->stream>>>(dx, dy, dz, dl, c.x, c.y, c.z, c.label, n, c.n_pad);
   HIP_TRY(h, hipGetLastError());
   c.present = true;
   c.cov_count = 0;
@@ -247,7 +282,6 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
   if (todo.empty()) return GORIO_OK;
   const int nj = (int)todo.size();
   std::vector<IndexJob> jobs(nj);
-  std::vector<unsigned int> bbinit = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   int max_pow2 = kSortTile, max_spad = 512, max_n = 1;
   for (int q = 0; q < nj; ++q) {
     gorio_apd* h = todo[q].first;
@@ -274,7 +308,6 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
       c.keys_cap = npow2;
     }
     if (!c.bb) HIP_TRY(h, hipMalloc(&c.bb, sizeof(unsigned int) * 6));
-    HIP_TRY(lead, hipMemcpyAsync(c.bb, bbinit.data(), sizeof(unsigned int) * 6, hipMemcpyHostToDevice, lead->stream));
     c.idx.n = c.n;
     c.idx.n_spad = n_spad;
     c.idx.n_tiles = n_spad / 32;
@@ -296,6 +329,7 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
   {
     StageTimer t(lead, 0);
     const IndexJob* dj = lead->d_ijobs;
+    bbox_init_kernel<<<(nj + 63) / 64, 64, 0, lead->stream>>>(dj, nj);
     bbox_kernel<<<dim3(std::min(64, (max_n + 255) / 256), nj), 256, 0, lead->stream>>>(dj);
     morton_kernel<<<dim3((max_pow2 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
     bitonic_tile_sort_kernel<<<dim3(max_pow2 / kSortTile, nj), 1024, 0, lead->stream>>>(dj);
@@ -451,6 +485,22 @@ void init_state(PairState& s, const double* T16) {
   for (int i = 0; i < 6; ++i) s.Hfin[i * 6 + i] = 1.0;  // final_hessian_.setIdentity(), LSQ:23
 }
 
+// batched helpers driven by the descriptor array
+__global__ __launch_bounds__(256) void arm_keys_kernel(const PairDesc* __restrict__ descs) {
+  const PairDesc& pd = descs[blockIdx.y];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < pd.src.n; i += gridDim.x * 256) pd.best_key[i] = ~0ull;
+}
+__global__ __launch_bounds__(64) void gather_states_kernel(const PairDesc* __restrict__ descs, PairState* __restrict__ out) {
+  const unsigned int* s = reinterpret_cast<const unsigned int*>(descs[blockIdx.x].state);
+  unsigned int* d = reinterpret_cast<unsigned int*>(out + blockIdx.x);
+  for (int q = threadIdx.x; q < (int)(sizeof(PairState) / 4); q += 64) d[q] = s[q];
+}
+__global__ __launch_bounds__(64) void scatter_states_kernel(const PairDesc* __restrict__ descs, const PairState* __restrict__ in) {
+  unsigned int* d = reinterpret_cast<unsigned int*>(descs[blockIdx.x].state);
+  const unsigned int* s = reinterpret_cast<const unsigned int*>(in + blockIdx.x);
+  for (int q = threadIdx.x; q < (int)(sizeof(PairState) / 4); q += 64) d[q] = s[q];
+}
+
 int ensure_batch(gorio_apd* lead, int count) {
   if (count > lead->desc_cap) {
     hipFree(lead->d_desc); hipFree(lead->d_states_batch);
@@ -477,7 +527,6 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
       if (h != lead) lead->err = h->err;
       return rc;
     }
-    if (h != lead) HIP_TRY(lead, hipStreamSynchronize(h->stream));
     rc = ensure_points(h, h->src.n);
     if (rc) return rc;
   }
@@ -515,13 +564,14 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     double T[16];
     for (int i = 0; i < 16; ++i) T[i] = (double)guesses[(size_t)q * 16 + i];  // LSQ:56
     init_state(states[q], T);
-    fill_desc(hs[q], descs[q], lead->d_states_batch + q, total_src_waves);
+    fill_desc(hs[q], descs[q], hs[q]->d_state, total_src_waves);
     if (descs[q].nn_splits > max_splits) max_splits = descs[q].nn_splits;
-    HIP_TRY(lead, hipMemsetAsync(hs[q]->best_key, 0xff, sizeof(unsigned long long) * hs[q]->src.n, lead->stream));
     hs[q]->corr_valid = true;
   }
   HIP_TRY(lead, hipMemcpyAsync(lead->d_desc, descs.data(), sizeof(PairDesc) * count, hipMemcpyHostToDevice, lead->stream));
   HIP_TRY(lead, hipMemcpyAsync(lead->d_states_batch, states.data(), sizeof(PairState) * count, hipMemcpyHostToDevice, lead->stream));
+  scatter_states_kernel<<<count, 64, 0, lead->stream>>>(lead->d_desc, lead->d_states_batch);
+  arm_keys_kernel<<<dim3(std::min(64, (max_n + 255) / 256), count), 256, 0, lead->stream>>>(lead->d_desc);
   HIP_TRY(lead, hipStreamSynchronize(lead->stream));
 
   const ApdConsts cst = make_consts(lead->params);
@@ -544,6 +594,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     }
     launched += todo_it;
     HIP_TRY(lead, hipGetLastError());
+    gather_states_kernel<<<count, 64, 0, lead->stream>>>(lead->d_desc, lead->d_states_batch);
     HIP_TRY(lead, hipMemcpyAsync(states.data(), lead->d_states_batch, sizeof(PairState) * count, hipMemcpyDeviceToHost, lead->stream));
     HIP_TRY(lead, hipStreamSynchronize(lead->stream));
     bool all_done = true;
@@ -559,10 +610,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     if (nr_iterations) nr_iterations[q] = s.nr_iterations;
     if (n_linearize) n_linearize[q] = s.n_linearize;
     if (s.lm_failed) hs[q]->err = "lm not converged!!";  // LSQ:72 prints this to stderr
-    // keep a copy of the final state in the handle's own slot so linearize/compute_error hooks can continue from it
-    HIP_TRY(lead, hipMemcpyAsync(hs[q]->d_state, lead->d_states_batch + q, sizeof(PairState), hipMemcpyDeviceToDevice, lead->stream));
   }
-  HIP_TRY(lead, hipStreamSynchronize(lead->stream));
   resolve_stage_events(lead);
   return GORIO_OK;
 }
@@ -612,7 +660,8 @@ int gorio_apd_create(gorio_apd_t** out, int device) {
   if (!h) return GORIO_ERR_ALLOC;
   h->device = device;
   gorio_apd_default_params(&h->params);
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc(&h->d_state, sizeof(PairState)) != hipSuccess ||
+  h->stream = device_stream(device);
+  if (!h->stream || hipMalloc(&h->d_state, sizeof(PairState)) != hipSuccess ||
       hipMalloc(&h->d_fit, sizeof(double) * 4) != hipSuccess) {
     delete h;
     return GORIO_ERR_NO_DEVICE;
@@ -630,7 +679,6 @@ void gorio_apd_destroy(gorio_apd_t* h) {
   hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
   hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_ijobs); hipFree(h->d_fit);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
-  if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
 

@@ -25,6 +25,15 @@ __device__ __forceinline__ float ord2f(unsigned int o) {
   return __uint_as_float(u);
 }
 
+__global__ void bbox_init_kernel(const IndexJob* __restrict__ jobs, int nj) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= nj) return;
+  for (int a = 0; a < 3; ++a) {
+    jobs[q].bb[a] = 0xffffffffu;
+    jobs[q].bb[3 + a] = 0u;
+  }
+}
+
 // grid: (blocks, jobs), block 256
 __global__ __launch_bounds__(256) void bbox_kernel(const IndexJob* __restrict__ jobs) {
   const IndexJob& jb = jobs[blockIdx.y];
@@ -70,10 +79,13 @@ __global__ __launch_bounds__(256) void morton_kernel(const IndexJob* __restrict_
   if (i < jb.n) {
     unsigned int q[3];
     const float v[3] = {jb.x[i], jb.y[i], jb.z[i]};
+    // ONE cell size for the three axes (cubic cells): tiles of consecutive codes are then compact in metres, not in bbox fractions
+    float ext = 1e-6f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ext = fmaxf(ext, ord2f(jb.bb[3 + a]) - ord2f(jb.bb[a]));
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float lo = ord2f(jb.bb[a]), hi = ord2f(jb.bb[3 + a]);
-      const float ext = fmaxf(hi - lo, 1e-6f);
+      const float lo = ord2f(jb.bb[a]);
       float t = (v[a] - lo) / ext * 2047.0f;
       t = fminf(fmaxf(t, 0.0f), 2047.0f);
       q[a] = (unsigned int)t;
@@ -234,8 +246,40 @@ __device__ __forceinline__ float box_bound(float qx, float qy, float qz, const f
 
 typedef const int __attribute__((address_space(4)))* scalar_ip;
 
+// wave-wide min / max (all lanes receive the result)
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// squared distance between two boxes (a lower bound of box_bound(q, tile) for every q inside the query box); the same un-fused
+// expression on per-axis gaps, so it is again monotone and never exceeds a real point distance in float arithmetic
+__device__ __forceinline__ float box_box_bound(const float (&qlo)[3], const float (&qhi)[3], float4 lo, float4 hi) {
+  const float gx = fmaxf(fmaxf(lo.x - qhi[0], qlo[0] - hi.x), 0.0f);
+  const float gy = fmaxf(fmaxf(lo.y - qhi[1], qlo[1] - hi.y), 0.0f);
+  const float gz = fmaxf(fmaxf(lo.z - qhi[2], qlo[2] - hi.z), 0.0f);
+  float r = gx * gx;
+  r = r + gy * gy;
+  r = r + gz * gz;
+  return r;
+}
+
+__device__ __forceinline__ float lane_f(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
+
+// Two-level test shared by both searches.  Coarse: 64 tile boxes at a time, one per lane (coalesced 32-byte loads), against the
+// box of the wave's 64 queries and the loosest per-lane bound -> ballot mask of candidate tiles.  Fine: for each candidate the
+// tile box is broadcast from the lane that holds it (v_readlane, no memory access) and tested per lane; only if some lane still
+// needs the tile are its 32 points fetched (wave-uniform scalar loads) and evaluated by all lanes.
+// visit order: 64-tile groups outward from `g0` (where near neighbours are expected) so the bound tightens early.
+
 // 1-NN of every source point in the target, pruned.  One lane = one source point taken in MORTON order (a wave's 64 queries are
-// spatially compact, so they agree on which tiles matter).  grid: (ceil(n_spad_src / 256), 1, pairs), block 256.
+// spatially compact).  grid: (ceil(n_spad_src / 256), 1, pairs), block 256.
 // Output: best_key[orig source index] = (float bits of d) << 32 | orig target index, exactly as nn_search_kernel.
 __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* __restrict__ descs, float bound_f) {
   const PairDesc& pd = descs[blockIdx.z];
@@ -245,46 +289,49 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   const SearchIndex& ti = pd.tgt.idx;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= si.n) return;
+  const int lane = threadIdx.x & 63;
   const int pq = p < si.n ? p : si.n - 1;
   float qx, qy, qz;
   transform_f(st->Tf, si.sx[pq], si.sy[pq], si.sz[pq], qx, qy, qz);
+  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
+  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
   const scalar_fp tx = as_scalar(ti.sx);
   const scalar_fp ty = as_scalar(ti.sy);
   const scalar_fp tz = as_scalar(ti.sz);
   const scalar_ip to = (scalar_ip)ti.orig;
-  const scalar_fp tb = as_scalar(ti.tbox);
-  const scalar_fp sb = as_scalar(ti.sbox);
+  const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(ti.tbox);
   // candidates farther than the correspondence gate can never be accepted (APD:183): start from the gate as the bound
   unsigned long long best = ((unsigned long long)__float_as_uint(bound_f) << 32) | 0xffffffffull;
   float bestd = bound_f;
-  // visit super tiles outward from the one at the same relative Morton position
-  const int ns = ti.n_super;
-  const int wave_first = (blockIdx.x * 256 + (threadIdx.x & ~63));
-  int s0 = (int)(((long)wave_first * ns) / (si.n > 0 ? si.n : 1));
-  s0 = __builtin_amdgcn_readfirstlane(s0 < ns ? s0 : ns - 1);
-  for (int v = 0; v < 2 * ns; ++v) {
+  const int ng = (ti.n_tiles + 63) / 64;
+  int g0 = (int)(((long)(blockIdx.x * 256 + (threadIdx.x & ~63)) * ng) / (si.n > 0 ? si.n : 1));
+  g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);
+  for (int v = 0; v < 2 * ng; ++v) {
     const int off = (v + 1) >> 1;
-    const int s = (v & 1) ? s0 - off : s0 + off;
-    if (s < 0 || s >= ns) continue;
-    float sbv[8];
+    const int g = (v & 1) ? g0 - off : g0 + off;
+    if (g < 0 || g >= ng) continue;
+    const int tl = g * 64 + lane;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    if (tl < ti.n_tiles) {
+      lo = tb4[2 * (size_t)tl];
+      hi = tb4[2 * (size_t)tl + 1];
+    }
+    const float wb = wave_max(bestd);
+    unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= wb);
+    while (mask) {
+      const int tlane = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+      if (__ballot(box_bound(qx, qy, qz, bx) <= bestd) == 0) continue;
+      const int j0 = (g * 64 + tlane) * 32;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sbv[q] = sb[s * 8 + q];
-    if (__ballot(box_bound(qx, qy, qz, sbv) <= bestd) == 0) continue;
-    const int t1 = min(s * 16 + 16, ti.n_tiles);
-    for (int t = s * 16; t < t1; ++t) {
-      float tbv[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) tbv[q] = tb[t * 8 + q];
-      if (__ballot(box_bound(qx, qy, qz, tbv) <= bestd) == 0) continue;
-      const int j0 = t * 32;
-#pragma unroll
-      for (int g = 0; g < 32; g += 8) {
+      for (int gg = 0; gg < 32; gg += 8) {
         float d[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + g + u], ty[j0 + g + u], tz[j0 + g + u]);
+        for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + gg + u], ty[j0 + gg + u], tz[j0 + gg + u]);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const unsigned long long key = ((unsigned long long)__float_as_uint(d[u]) << 32) | (unsigned int)to[j0 + g + u];
+          const unsigned long long key = ((unsigned long long)__float_as_uint(d[u]) << 32) | (unsigned int)to[j0 + gg + u];
           best = key < best ? key : best;
         }
       }
@@ -319,14 +366,16 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restric
   const int n = si.n;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= n) return;
+  const int lane = threadIdx.x & 63;
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
+  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
+  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
   const scalar_fp tx = as_scalar(si.sx);
   const scalar_fp ty = as_scalar(si.sy);
   const scalar_fp tz = as_scalar(si.sz);
   const scalar_ip to = (scalar_ip)si.orig;
-  const scalar_fp tb = as_scalar(si.tbox);
-  const scalar_fp sb = as_scalar(si.sbox);
+  const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
   float bd[K];
   int bi[K];
 #pragma unroll
@@ -334,45 +383,44 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restric
     bd[t] = INFINITY;
     bi[t] = 0x7fffffff;
   }
-  const int ns = si.n_super;
-  const int s0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + (threadIdx.x & ~63)) / 512);
-  for (int v = 0; v < 2 * ns; ++v) {
+  const int ng = (si.n_tiles + 63) / 64;
+  const int own_tile = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + (threadIdx.x & ~63)) / 32);
+  const int g0 = own_tile / 64;
+  for (int v = 0; v < 2 * ng; ++v) {
     const int off = (v + 1) >> 1;
-    const int s = (v & 1) ? s0 - off : s0 + off;
-    if (s < 0 || s >= ns) continue;
-    float sbv[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sbv[q] = sb[s * 8 + q];
-    if (__ballot(box_bound(qx, qy, qz, sbv) <= bd[K - 1]) == 0) continue;
-    // within the own super tile start at the own tile and walk outward, elsewhere in order
-    const int tbase = s * 16;
-    const int own = (s == s0) ? (__builtin_amdgcn_readfirstlane(blockIdx.x * 256 + (threadIdx.x & ~63)) / 32) - tbase : 0;
-    for (int w = 0; w < 32; ++w) {
-      int t;
-      if (s == s0) {
-        const int o2 = (w + 1) >> 1;
-        t = (w & 1) ? own - o2 : own + o2;
-        if (t < 0 || t >= 16) continue;
-      } else {
-        if (w >= 16) break;
-        t = w;
+    const int g = (v & 1) ? g0 - off : g0 + off;
+    if (g < 0 || g >= ng) continue;
+    const int tl = g * 64 + lane;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    if (tl < si.n_tiles) {
+      lo = tb4[2 * (size_t)tl];
+      hi = tb4[2 * (size_t)tl + 1];
+    }
+    // in the own group take the own tiles first (they fill the list with true neighbours), then the rest
+    for (int phase = (g == g0 ? 0 : 1); phase < 2; ++phase) {
+      const float wb = wave_max(bd[K - 1]);
+      unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= wb);
+      if (g == g0) {
+        const int ol = own_tile - g * 64;
+        const unsigned long long near = (((ol + 3) >= 64) ? ~0ull : ((1ull << (ol + 3)) - 1ull)) & ~((ol >= 1) ? ((1ull << (ol - 1)) - 1ull) : 0ull);  // tiles ol-1 .. ol+2
+        mask = phase == 0 ? (mask & near) : (mask & ~near);
       }
-      t += tbase;
-      if (t >= si.n_tiles) continue;
-      float tbv[8];
+      while (mask) {
+        const int tlane = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+        if (__ballot(box_bound(qx, qy, qz, bx) <= bd[K - 1]) == 0) continue;
+        const int j0 = (g * 64 + tlane) * 32;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) tbv[q] = tb[t * 8 + q];
-      if (__ballot(box_bound(qx, qy, qz, tbv) <= bd[K - 1]) == 0) continue;
-      const int j0 = t * 32;
+        for (int gg = 0; gg < 32; gg += 8) {
+          float d[8];
 #pragma unroll
-      for (int g = 0; g < 32; g += 8) {
-        float d[8];
+          for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + gg + u], ty[j0 + gg + u], tz[j0 + gg + u]);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + g + u], ty[j0 + g + u], tz[j0 + g + u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int oi = to[j0 + g + u];
-          if (d[u] < bd[K - 1] || (d[u] == bd[K - 1] && oi < bi[K - 1])) topk_insert_lex<K>(bd, bi, d[u], oi);
+          for (int u = 0; u < 8; ++u) {
+            const int oi = to[j0 + gg + u];
+            if (d[u] < bd[K - 1] || (d[u] == bd[K - 1] && oi < bi[K - 1])) topk_insert_lex<K>(bd, bi, d[u], oi);
+          }
         }
       }
     }

@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -16,6 +19,8 @@
 using namespace gorio;
 
 namespace {
+
+constexpr int kEvalSplit = 6;  // workgroups per window in the residual / Jacobian evaluators
 
 thread_local std::string g_err;
 thread_local double g_stage_s[5] = {0, 0, 0, 0, 0};
@@ -76,12 +81,16 @@ void slice(const double* t, int n, double from, double to, int& i0, int& cnt) {
 }
 
 // carve one window's slab; returns the number of doubles used (called once with base == nullptr for sizing)
-size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* base) {
+size_t input_doubles(const gorio_ugpm_window& w, const HostWin& h) { return (size_t)h.G * 4 + (size_t)h.V * 4 + (size_t)w.n_infer + (size_t)h.S; }
+
+// `in` = this window's slice of the batch-wide contiguous input region (one upload for the whole batch), `outp` = its slice of
+// the batch-wide output region (one download)
+size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* base, double* in, double* outp) {
   double* p = base;
   auto take = [&](size_t cnt) { double* r = p; p += cnt; return r; };
+  auto take_in = [&](size_t cnt) { double* r = in; in += cnt; return r; };
   const size_t S = h.S, G = h.G, V = h.V, n = 3 * S, mrot = 3 * S + 3 * G, mvel = 3 * V + 3 * S, mc = 3 * G + 3 * V, nc = 6 * S;
-  // inputs first, contiguous: gyr_t, gyr SoA, vel_t, vel SoA, infer_t, state_t (uploaded with one copy)
-  u.gyr_t = take(G); u.gyr = take(3 * G); u.vel_t = take(V); u.vel = take(3 * V); u.infer_t = take(w.n_infer); u.state_t = take(S);
+  u.gyr_t = take_in(G); u.gyr = take_in(3 * G); u.vel_t = take_in(V); u.vel = take_in(3 * V); u.infer_t = take_in(w.n_infer); u.state_t = take_in(S);
   u.Rq = take(5 * 2 * S * 9); u.Rstart = take(5 * 9); u.velr = take(3 * V); u.dp = take(2 * S * 3); u.r0 = take(5 * S * 3); u.r1 = take(5 * S * 3);
   u.s_dr = take(3 * S); u.s_vel = take(3 * S); u.hyper = take(24);
   u.d_r_dt_local = take(S * 3); u.d_r_dt_local_shift = take(S * 3); u.delta_r_time = take(S * 3); u.delta_r_bw = take(3 * S * 3); u.d_r_bw_local_shift = take(3 * S * 3);
@@ -92,7 +101,7 @@ size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* b
   if (w.correlate) { u.Jc = take(mc * nc); u.Ac = take(nc * nc); }
   u.dsc = take(nc);
   u.alpha = take(6 * S); u.state_r = take(3 * S); u.d_state_bw = take(3 * S * 3); u.d_d_r_dt = take(3 * S); u.d_vel_bv = take(3 * S * 3); u.d_vel_bw = take(3 * S * 3);
-  u.d_vel_dt = take(3 * S); u.out = take((size_t)w.n_infer * 83); u.lmc = take(16);
+  u.d_vel_dt = take(3 * S); u.out = outp; u.lmc = take(16);
   return ((size_t)(p - base) + 31) / 32 * 32;
 }
 
@@ -153,13 +162,33 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     hipFree(c.ws); hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag);
     c = Ctx();
     c.device = device;
-    UHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    const char* split = std::getenv("GORIO_CU_SPLIT");  // see apd_api.hip: this stream gets the reserved k/8 of the CUs
+    const int k = split ? std::atoi(split) : 0;
+    bool made = false;
+    if (k >= 1 && k <= 7) {
+      uint32_t mask[8];
+      for (int w = 0; w < 8; ++w) {
+        mask[w] = 0;
+        for (int b = 0; b < 32; ++b)
+          if (((w * 32 + b) % 8) < k) mask[w] |= (1u << b);
+      }
+      made = hipExtStreamCreateWithCUMask(&c.stream, 8, mask) == hipSuccess;
+    }
+    if (!made) {  // highest priority: these are many small latency-bound launches that should not queue behind the scan matcher's large grids
+      int lo = 0, hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi) == hipSuccess) made = true;
+    }
+    if (!made) UHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   }
   for (int i = 0; i < 5; ++i) { g_stage_s[i] = 0; g_stage_n[i] = 0; }
+  const bool trace = std::getenv("GORIO_UGPM_TRACE") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tt0 = tnow();
+  double tt1 = 0, tt2 = 0, tt3 = 0;
 
   // ---- host bookkeeping per window (preint.h:1532-1556, 766-811): no numerics beyond the state time line
   std::vector<HostWin> hw(n_windows);
-  size_t total_doubles = 0;
+  size_t total_doubles = 0, total_in = 0;
   int total_infer = 0, max_infer = 0, max_S = 0;
   int first_error = 0;
   std::string first_error_msg;
@@ -197,9 +226,12 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     if (h.G < 2 || h.V < 2) { win_fail(i, GORIO_UGPM_ERR_RANGE, "fewer than 2 gyro / velocity samples inside the state window"); continue; }
     max_S = std::max(max_S, h.S);
     UgpmWin dummy;
-    h.ws_doubles = carve(w, h, dummy, nullptr);
+    h.ws_doubles = carve(w, h, dummy, nullptr, nullptr, nullptr);
+    total_in += (input_doubles(w, h) + 3) / 4 * 4;
     total_doubles += h.ws_doubles;
   }
+  const size_t total_out = (size_t)total_infer * 83;
+  total_doubles += total_in + total_out + 64;
   if (total_doubles > c.ws_cap) {
     hipFree(c.ws);
     c.ws = nullptr;
@@ -220,9 +252,12 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   std::vector<UgpmWin> dw(n_windows);
   std::vector<double> stage_in;
   std::vector<int> ints(17 * (size_t)n_windows, 0);
-  double* base = c.ws;
-  std::vector<std::pair<double*, size_t>> uploads;  // (device dst, offset into stage_in) with lengths kept alongside
-  std::vector<size_t> upload_len;
+  double* in_region = c.ws;
+  double* out_region = c.ws + total_in;
+  double* base = out_region + (total_out + 31) / 32 * 32;
+  stage_in.assign(total_in, 0.0);
+  size_t in_off = 0, out_off = 0;
+  std::vector<size_t> out_offs(n_windows, 0);
   for (int i = 0; i < n_windows; ++i) {
     const gorio_ugpm_window& w = windows[i];
     HostWin& h = hw[i];
@@ -232,23 +267,19 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     u.status = c.d_ints + 17 * (size_t)i + 16;
     ints[17 * (size_t)i + 16] = h.status;
     u.n_infer = std::max(0, w.n_infer);
-    if (h.status != 0) {
-      u.out = nullptr;
-      continue;
-    }
-    carve(w, h, u, base);
+    out_offs[i] = out_off;
+    u.out = out_region + out_off;
+    out_off += (size_t)u.n_infer * 83;
+    if (h.status != 0) continue;
+    carve(w, h, u, base, in_region + in_off, u.out);
     const size_t S = h.S, G = h.G, V = h.V;
-    double* d_gt = const_cast<double*>(u.gyr_t);
     u.G = h.G; u.V = h.V; u.S = h.S;
     u.correlate = w.correlate ? 1 : 0; u.overlap = w.overlap;
     u.start_t = w.start_t; u.state_freq = h.state_freq; u.gyr_var = w.gyr_var; u.vel_var = w.vel_var;
     for (int a = 0; a < 3; ++a) { u.gyr_bias[a] = w.gyr_bias[a]; u.vel_bias[a] = w.vel_bias[a]; }
     u.vel_bias_std = w.vel_bias_std; u.gyr_bias_std = w.gyr_bias_std;
     base += h.ws_doubles;
-    // stage inputs contiguously: gyr_t, gyr SoA, vel_t, vel SoA, infer_t, state_t (they are contiguous in the slab)
-    const size_t off = stage_in.size();
-    stage_in.resize(off + G + 3 * G + V + 3 * V + (size_t)w.n_infer + S);
-    double* s = stage_in.data() + off;
+    double* s = stage_in.data() + in_off;
     for (size_t k = 0; k < G; ++k) s[k] = w.gyr_t[h.g0 + k];
     s += G;
     for (int a = 0; a < 3; ++a)
@@ -262,14 +293,14 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     for (int k = 0; k < w.n_infer; ++k) s[k] = w.infer_t[k];
     s += w.n_infer;
     for (size_t k = 0; k < S; ++k) s[k] = h.state_t[k];
-    uploads.emplace_back(d_gt, off);
-    upload_len.push_back(G + 3 * G + V + 3 * V + (size_t)w.n_infer + S);
+    in_off += (input_doubles(w, h) + 3) / 4 * 4;
   }
-  for (size_t q = 0; q < uploads.size(); ++q)
-    UHIP(hipMemcpyAsync(uploads[q].first, stage_in.data() + uploads[q].second, sizeof(double) * upload_len[q], hipMemcpyHostToDevice, c.stream));
+  if (total_in) UHIP(hipMemcpyAsync(in_region, stage_in.data(), sizeof(double) * total_in, hipMemcpyHostToDevice, c.stream));
   UHIP(hipMemcpyAsync(c.d_wins, dw.data(), sizeof(UgpmWin) * n_windows, hipMemcpyHostToDevice, c.stream));
   UHIP(hipMemcpyAsync(c.d_ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice, c.stream));
+  tt1 = tnow();
   UHIP(hipStreamSynchronize(c.stream));  // staging vectors are pageable
+  tt2 = tnow();
 
   const int nw = n_windows;
   const int max_G = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.G); return m; }();
@@ -296,16 +327,16 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     for (int problem = 0; problem < 2; ++problem) {  // ceres::Solve #1 (rotation) and #2 (velocity), preint.h:943-967
       Stage st(c, 3);
       ug::lm_begin_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, problem);
-      if (problem == 0) ug::rot_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 2);
-      else ug::vel_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 2);
+      if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 2);
+      else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 2);
       ug::ata_kernel<<<dim3(tiles_n, tiles_n, nw), 256, 0, c.stream>>>(c.d_wins, problem);
       for (int it = 0; it <= 51; ++it) {
         ug::lm_step_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
-        if (problem == 0) ug::rot_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 0);
-        else ug::vel_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 0);
+        if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
+        else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
         ug::lm_decide_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
-        if (problem == 0) ug::rot_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 1);
-        else ug::vel_eval_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, 1);
+        if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
+        else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
         ug::ata_kernel<<<dim3(tiles_n, tiles_n, nw), 256, 0, c.stream>>>(c.d_wins, problem);
         if ((it & 1) == 1) {  // poll the done flags every other iteration
           UHIP(hipMemcpyAsync(flags.data(), c.d_ints, sizeof(int) * flags.size(), hipMemcpyDeviceToHost, c.stream));
@@ -324,22 +355,13 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     }
     UHIP(hipGetLastError());
   }
+  tt3 = tnow();
   // ---- results
   std::vector<int> fin(17 * (size_t)nw);
   std::vector<double> dg(4 * (size_t)nw);
   UHIP(hipMemcpyAsync(fin.data(), c.d_ints, sizeof(int) * fin.size(), hipMemcpyDeviceToHost, c.stream));
   UHIP(hipMemcpyAsync(dg.data(), c.d_diag, sizeof(double) * dg.size(), hipMemcpyDeviceToHost, c.stream));
-  size_t rec = 0;
-  for (int i = 0; i < nw; ++i) {
-    const int ni = std::max(0, windows[i].n_infer);
-    if (hw[i].status == 0) {
-      UHIP(hipMemcpyAsync(reinterpret_cast<double*>(out) + rec * 83, dw[i].out, sizeof(double) * 83 * ni, hipMemcpyDeviceToHost, c.stream));
-    } else {
-      double* o = reinterpret_cast<double*>(out) + rec * 83;
-      for (size_t k = 0; k < (size_t)ni * 83; ++k) o[k] = std::numeric_limits<double>::quiet_NaN();
-    }
-    rec += ni;
-  }
+  if (total_out) UHIP(hipMemcpyAsync(reinterpret_cast<double*>(out), out_region, sizeof(double) * total_out, hipMemcpyDeviceToHost, c.stream));
   UHIP(hipStreamSynchronize(c.stream));
   for (size_t q = 0; q < c.ev.size(); ++q) {
     float ms = 0.f;
@@ -353,6 +375,10 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   c.ev.clear();
   c.ev_stage.clear();
   for (int i = 0; i < nw; ++i) {
+    if (hw[i].status != 0) {  // rejected on the host: its records were never written
+      double* o = reinterpret_cast<double*>(out) + out_offs[i];
+      for (size_t k = 0; k < (size_t)std::max(0, windows[i].n_infer) * 83; ++k) o[k] = std::numeric_limits<double>::quiet_NaN();
+    }
     int st = hw[i].status != 0 ? hw[i].status : fin[17 * (size_t)i + 16];
     if (st != 0 && hw[i].status == 0 && !first_error) {
       first_error = st;
@@ -366,6 +392,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       d.status = st; d.state_freq = hw[i].state_freq;
     }
   }
+  if (trace) std::fprintf(stderr, "[ugpm trace] prep %.3f ms, upload sync %.3f ms, kernels+polls %.3f ms, results %.3f ms\n", (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (tt3 - tt2) * 1e3, (tnow() - tt3) * 1e3);
   if (first_error) return ufail(first_error, first_error_msg);
   return GORIO_UGPM_OK;
 }

@@ -218,49 +218,64 @@ __device__ void lpm_rotation(const UgpmWin& w, int variant) {
     if (variant - 2 == a) d += kBw;
     return d;
   };
-  // linearInterpolation state per axis (math_utils.h:487-532)
+  // linearInterpolation state per axis (math_utils.h:487-532); the bracketing samples are cached in registers and refreshed only
+  // when the segment pointer advances
   int ptr[3] = {0, 0, 0};
-  double al[3], be[3];
+  double al[3], be[3], tlo[3], thi[3], dhi[3];
   for (int a = 0; a < 3; ++a) {
-    al[a] = (gd(a, 1) - gd(a, 0)) / (gt(1) - gt(0));
-    be[a] = gd(a, 0) - (al[a] * gt(0));
+    tlo[a] = gt(0);
+    thi[a] = gt(1);
+    const double d0 = gd(a, 0);
+    dhi[a] = gd(a, 1);
+    al[a] = (dhi[a] - d0) / (thi[a] - tlo[a]);
+    be[a] = d0 - (al[a] * tlo[a]);
   }
   const double gt0 = gt(0);
   auto interp = [&](double t, double* out) {
     for (int a = 0; a < 3; ++a) {
       if (t > gt0) {
         while (ptr[a] != (G - 2)) {
-          if ((t <= gt(ptr[a] + 1)) && (t > gt(ptr[a]))) break;
+          if ((t <= thi[a]) && (t > tlo[a])) break;
           ptr[a]++;
-          al[a] = (gd(a, ptr[a] + 1) - gd(a, ptr[a])) / (gt(ptr[a] + 1) - gt(ptr[a]));
-          be[a] = gd(a, ptr[a]) - (al[a] * gt(ptr[a]));
+          const double d0 = dhi[a];
+          tlo[a] = thi[a];
+          thi[a] = gt(ptr[a] + 1);
+          dhi[a] = gd(a, ptr[a] + 1);
+          al[a] = (dhi[a] - d0) / (thi[a] - tlo[a]);
+          be[a] = d0 - (al[a] * tlo[a]);
         }
       }
       out[a] = al[a] * t + be[a];
     }
   };
-  // streaming merge; ties are emitted in the list order 3, 0, 1, 2, 4, 5 so that nothing captured precedes the LPM start stamp
-  const int order[6] = {3, 0, 1, 2, 4, 5};
-  int p[6] = {0, 0, 0, 0, 0, 0};
+  // streaming merge; ties are emitted in the list order 3, 0, 1, 2, 4, 5 so that nothing captured precedes the LPM start stamp.
+  // The head of every list is cached in a register and refreshed only when that list advances (one load per step).
+  int p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0;
+  const double kInf = 1.7976931348623157e308;
+  double h0 = nl[0] > 0 ? val(0, 0) : kInf, h1 = nl[1] > 0 ? val(1, 0) : kInf, h2 = val(2, 0), h3 = val(3, 0);
+  double h4 = nl[4] > 0 ? val(4, 0) : kInf, h5 = nl[5] > 0 ? val(5, 0) : kInf;
   int total = 0;
   for (int l = 0; l < 6; ++l) total += nl[l];
   M3 R = eye3();
   double t_prev = 0.0, w_prev[3] = {0, 0, 0};
   double* Rq = w.Rq + (size_t)variant * 2 * S * 9;
   for (int step = 0; step < total; ++step) {
-    int bl = -1;
-    double bt = 0.0;
-    for (int o = 0; o < 6; ++o) {
-      const int l = order[o];
-      if (p[l] < nl[l]) {
-        const double c = val(l, p[l]);
-        if (bl < 0 || c < bt) {
-          bl = l;
-          bt = c;
-        }
-      }
+    int bl = 3;
+    double bt = h3;
+    if (h0 < bt) { bl = 0; bt = h0; }
+    if (h1 < bt) { bl = 1; bt = h1; }
+    if (h2 < bt) { bl = 2; bt = h2; }
+    if (h4 < bt) { bl = 4; bt = h4; }
+    if (h5 < bt) { bl = 5; bt = h5; }
+    int idx;
+    switch (bl) {
+      case 0: idx = p0++; h0 = p0 < nl[0] ? val(0, p0) : kInf; break;
+      case 1: idx = p1++; h1 = p1 < nl[1] ? val(1, p1) : kInf; break;
+      case 2: idx = p2++; h2 = p2 < nl[2] ? val(2, p2) : kInf; break;
+      case 3: idx = p3++; h3 = p3 < nl[3] ? val(3, p3) : kInf; break;
+      case 4: idx = p4++; h4 = p4 < nl[4] ? val(4, p4) : kInf; break;
+      default: idx = p5++; h5 = p5 < nl[5] ? val(5, p5) : kInf; break;
     }
-    const int idx = p[bl]++;
     if (step > 0) {  // rotIterativeIntegration, preint.h:421-453 / 496-506
       const double dt = bt - t_prev;
       R = mmul(R, expMap(v3(w_prev[0] * dt, w_prev[1] * dt, w_prev[2] * dt)));
@@ -664,16 +679,19 @@ __global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ w
     A[q] = s;
   }
   __syncthreads();
+  double* Kc = w.JtJ + (size_t)c * S * S;   // scratch: the Gram matrix itself (JtJ / lhs are idle until the LM stage, 9 S^2 each)
+  for (int q = threadIdx.x; q < S * S; q += blockDim.x) Kc[q] = se_k(st[q / S], st[q % S], l2, sf2);
+  __syncthreads();
   for (int q = threadIdx.x; q < S * S; q += blockDim.x) {  // K K^-1, preint.h:838
     const int i = q / S, j = q % S;
     double s = 0.0;
-    for (int k = 0; k < S; ++k) s += se_k(st[i], st[k], l2, sf2) * A[(size_t)k * S + j];
+    for (int k = 0; k < S; ++k) s += Kc[(size_t)i * S + k] * A[(size_t)k * S + j];
     B[q] = s;
   }
   __syncthreads();
   for (int j = threadIdx.x; j < S; j += blockDim.x) {  // preint.h:846-864
     double s = 0.0;
-    for (int k = 0; k < S; ++k) s += B[(size_t)j * S + k] * se_k(st[k], st[j], l2, sf2);
+    for (int k = 0; k < S; ++k) s += B[(size_t)j * S + k] * Kc[(size_t)k * S + j];
     double v = -s + sf2 + sz2;
     if (v <= 0) v = sz2;
     w.var[c * S + j] = v;
@@ -684,10 +702,13 @@ __global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ w
   }
   if (c < 3) {  // K_int K^-1, preint.h:842-844
     double* C = w.KintKinv + (size_t)c * S * S;
+    double* Ki = w.lhs + (size_t)c * S * S;  // scratch: K_int
+    for (int q = threadIdx.x; q < S * S; q += blockDim.x) Ki[q] = se_kint(w.start_t, st[q / S], st[q % S], l2, sf2);
+    __syncthreads();
     for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
       const int i = q / S, j = q % S;
       double s = 0.0;
-      for (int k = 0; k < S; ++k) s += se_kint(w.start_t, st[i], st[k], l2, sf2) * A[(size_t)k * S + j];
+      for (int k = 0; k < S; ++k) s += Ki[(size_t)i * S + k] * A[(size_t)k * S + j];
       C[q] = s;
     }
   }
@@ -772,6 +793,7 @@ __device__ void gpnorm_rows(const UgpmWin& w, int ch, const double* __restrict__
   const int S = w.S;
   const double* KK = w.KKinv + (size_t)ch * S * S;
   const double* wt = w.wgp + (size_t)ch * S;
+  if ((int)blockIdx.y != ch % (int)gridDim.y) return;  // one of the workgroups of this window takes the channel
   for (int i = threadIdx.x; i < S; i += blockDim.x) res[i] = (row_dot(KK + (size_t)i * S, s, S) - s[i]) * wt[i];
   if (writeJ)
     for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
@@ -781,7 +803,7 @@ __device__ void gpnorm_rows(const UgpmWin& w, int ch, const double* __restrict__
 }
 
 // Problem #1 (preint.h:872-952): unknowns x = [s_dr0 | s_dr1 | s_dr2] (3S); rows = 3 GpNorm blocks (3S) then RotCost (3G).
-// grid: (windows), block 256.  mode: 0 residual at x_new -> res_new; 1 residual + Jacobian at x -> res, Jrot; 2 as 1 and also
+// grid: (windows, splits), block 256: the workgroups of one window share its samples.  mode: 0 residual at x_new -> res_new; 1 residual + Jacobian at x -> res, Jrot; 2 as 1 and also
 // (re)writes the constant GpNorm blocks and zeroes the rest (first evaluation).
 __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict__ wins, int mode) {
   const UgpmWin& w = wins[blockIdx.x];
@@ -791,11 +813,15 @@ __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict
   const double* x = mode == 0 ? w.lmv + 6 * (size_t)n : w.lmv + 5 * (size_t)n;
   double* res = mode == 0 ? w.res_new : w.res;
   double* J = w.Jrot;
-  if (mode == 2)
-    for (size_t q = threadIdx.x; q < (size_t)(3 * S + 3 * G) * n; q += blockDim.x) J[q] = 0.0;
+  const int i_lo = (int)(((long)G * blockIdx.y) / gridDim.y), i_hi = (int)(((long)G * (blockIdx.y + 1)) / gridDim.y);  // this workgroup's samples
+  if (mode == 2) {  // zero the rows this workgroup owns: its GpNorm channel block and its sample rows
+    for (int c = 0; c < 3; ++c)
+      if ((int)blockIdx.y == c % (int)gridDim.y)
+        for (size_t q = threadIdx.x; q < (size_t)S * n; q += blockDim.x) J[(size_t)c * S * n + q] = 0.0;
+  }
   __syncthreads();
   for (int c = 0; c < 3; ++c) gpnorm_rows(w, c, x + (size_t)c * S, res + (size_t)c * S, J + (size_t)c * S * n, n, c * S, mode == 2);
-  for (int i = threadIdx.x; i < G; i += blockDim.x) {  // cost_functions.h:201-253
+  for (int i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {  // cost_functions.h:201-253
     double rot[3], drv[3];
     for (int c = 0; c < 3; ++c) {
       drv[c] = row_dot(w.KsKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
@@ -819,8 +845,8 @@ __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict
   }
   if (mode == 0) return;
   __syncthreads();
-  for (size_t q = threadIdx.x; q < (size_t)G * 3 * n; q += blockDim.x) {  // cost_functions.h:229-246
-    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / n) % 3), i = (int)(q / ((size_t)3 * n));
+  for (size_t q = threadIdx.x; q < (size_t)(i_hi - i_lo) * 3 * n; q += blockDim.x) {  // cost_functions.h:229-246
+    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / n) % 3), i = i_lo + (int)(q / ((size_t)3 * n));
     const double* st = w.sample_tmp + (size_t)i * 24;
     J[((size_t)(3 * S + 3 * i + a)) * n + c * S + j] = st[a * 6 + c] * w.KsIntKinv[((size_t)c * G + i) * S + j] + st[a * 6 + c + 3] * w.KsKinv[((size_t)c * G + i) * S + j];
   }
@@ -844,12 +870,17 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
   const double* x = mode == 0 ? w.lmv + 6 * (size_t)n : w.lmv + 5 * (size_t)n;
   double* res = mode == 0 ? w.res_new : w.res;
   double* J = w.Jvel;
-  if (mode == 2)
-    for (size_t q = threadIdx.x; q < (size_t)(3 * S + 3 * V) * n; q += blockDim.x) J[q] = 0.0;
+  const int i_lo = (int)(((long)V * blockIdx.y) / gridDim.y), i_hi = (int)(((long)V * (blockIdx.y + 1)) / gridDim.y);
+  if (mode == 2) {
+    for (int c = 0; c < 3; ++c)
+      if ((int)blockIdx.y == (3 + c) % (int)gridDim.y)
+        for (size_t q = threadIdx.x; q < (size_t)S * n; q += blockDim.x) J[((size_t)3 * V + (size_t)c * S) * n + q] = 0.0;
+    for (size_t q = threadIdx.x; q < (size_t)(i_hi - i_lo) * 3 * n; q += blockDim.x) J[(size_t)i_lo * 3 * n + q] = 0.0;
+  }
   __syncthreads();
   for (int c = 0; c < 3; ++c) gpnorm_rows(w, 3 + c, x + (size_t)c * S, res + 3 * V + (size_t)c * S, J + ((size_t)3 * V + (size_t)c * S) * n, n, c * S, mode == 2);
   const double wgt = sqrt(1.0 / w.vel_var);
-  for (int i = threadIdx.x; i < V; i += blockDim.x) {  // cost_functions.h:323-381
+  for (int i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {  // cost_functions.h:323-381
     const V3 rv = vel_rot_vec(w, i);
     const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
     double vel[3];
@@ -864,8 +895,8 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
   }
   if (mode == 0) return;
   __syncthreads();
-  for (size_t q = threadIdx.x; q < (size_t)V * 3 * n; q += blockDim.x) {  // cost_functions.h:372-376
-    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / n) % 3), i = (int)(q / ((size_t)3 * n));
+  for (size_t q = threadIdx.x; q < (size_t)(i_hi - i_lo) * 3 * n; q += blockDim.x) {  // cost_functions.h:372-376
+    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / n) % 3), i = i_lo + (int)(q / ((size_t)3 * n));
     J[((size_t)(3 * i + a)) * n + c * S + j] = wgt * w.sample_tmp[(size_t)i * 24 + a * 3 + c] * w.KvelKinv[((size_t)c * V + i) * S + j];
   }
 }
@@ -1111,10 +1142,12 @@ __global__ __launch_bounds__(256) void lm_step_kernel(const UgpmWin* __restrict_
   double mcc = 0.0, sn = 0.0;
   if (valid) {  // model cost change -(J d)^T (r + J d / 2) = -(d.g + d^T (J^T J) d / 2)
     double acc = 0.0;
+    for (size_t q = threadIdx.x; q < (size_t)n * n; q += blockDim.x) {  // 0.5 d^T (J^T J) d, coalesced over the matrix
+      const int i = (int)(q / n), j = (int)(q % n);
+      acc += 0.5 * delta[i] * w.JtJ[q] * delta[j];
+    }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      double t = 0.0;
-      for (int j = 0; j < n; ++j) t += w.JtJ[(size_t)i * n + j] * delta[j];
-      acc += delta[i] * (g[i] + 0.5 * t);
+      acc += delta[i] * g[i];
       sn += delta[i] * delta[i];
       xn[i] = x[i] + delta[i];
     }

@@ -20,10 +20,10 @@ class UgpmWindow(C.Structure):
     """gorio_ugpm_window (include/gorio_ugpm.h)."""
 
     _fields_ = [
-        ("gyr_t", C.POINTER(C.c_double)), ("gyr", C.POINTER(C.c_double)), ("n_gyr", C.c_int),
-        ("vel_t", C.POINTER(C.c_double)), ("vel", C.POINTER(C.c_double)), ("n_vel", C.c_int),
+        ("gyr_t", C.c_void_p), ("gyr", C.c_void_p), ("n_gyr", C.c_int),
+        ("vel_t", C.c_void_p), ("vel", C.c_void_p), ("n_vel", C.c_int),
         ("gyr_var", C.c_double), ("vel_var", C.c_double), ("start_t", C.c_double),
-        ("infer_t", C.POINTER(C.c_double)), ("n_infer", C.c_int), ("type", C.c_int),
+        ("infer_t", C.c_void_p), ("n_infer", C.c_int), ("type", C.c_int),
         ("min_freq", C.c_double), ("quantum", C.c_double), ("state_freq", C.c_double),
         ("correlate", C.c_int), ("overlap", C.c_int),
         ("gyr_bias", C.c_double * 3), ("vel_bias", C.c_double * 3),
@@ -37,7 +37,8 @@ class UgpmDiag(C.Structure):
 
 
 def _dp(a):
-    return a.ctypes.data_as(C.POINTER(C.c_double))
+    """Address of a contiguous float64 array (ndarray.ctypes is slow once torch is imported: ~40 us per access)."""
+    return a.__array_interface__["data"][0]
 
 
 def unpack(rec):
@@ -80,7 +81,7 @@ def ugpm_preint_batch(windows, device=0, infer_t=None, type=UGPM, state_freq=50.
         counts.append(len(q))
     out = np.zeros((sum(counts), REC))
     diag = (UgpmDiag * n)()
-    rc = lib.gorio_ugpm_preint_batch(arr, n, _dp(out), diag, int(device))
+    rc = lib.gorio_ugpm_preint_batch(arr, n, C.c_void_p(_dp(out)), diag, int(device))
     if rc < 0:
         msg = lib.gorio_ugpm_last_error()
         raise GorioError(rc, msg.decode() if msg else "")
