@@ -28,6 +28,7 @@ class Params(C.Structure):
         ("lm_max_iterations", C.c_int),
         ("lm_init_lambda_factor", C.c_double),
         ("num_threads", C.c_int),
+        ("search", C.c_int),
     ]
 
 
@@ -77,12 +78,13 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def knn_self(xyz, k, num_threads=0):
+def knn_self(xyz, k, num_threads=0, kdtree=False):
     xyz = _f32(xyz)
     n = xyz.shape[0]
     idx = np.empty((n, k), np.int32)
     sqd = np.empty((n, k), np.float32)
-    rc = lib().apdo_knn_self(_p(xyz, C.c_float), n, k, _p(idx, C.c_int), _p(sqd, C.c_float), num_threads)
+    fn = lib().apdo_knn_self_kdtree if kdtree else lib().apdo_knn_self
+    rc = fn(_p(xyz, C.c_float), n, k, _p(idx, C.c_int), _p(sqd, C.c_float), num_threads)
     if rc != 0:
         raise ValueError(f"apdo_knn_self rc={rc} (needs n >= k)")
     return idx, sqd

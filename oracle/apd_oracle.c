@@ -71,6 +71,7 @@ typedef struct {
   int lm_max_iterations;          /* LSQ:19 (10) */
   double lm_init_lambda_factor;   /* LSQ:20 (1e-9) */
   int num_threads;                /* APD:34-42; 0 => omp max */
+  int search;                     /* 0 = exhaustive scan (bit-exact index oracle), 1 = exact kd-tree (what pcl::search::KdTree does, APD:178, 364) */
 } apdo_params;
 
 void apdo_default_params(apdo_params* p) {
@@ -87,6 +88,7 @@ void apdo_default_params(apdo_params* p) {
   p->lm_max_iterations = 10;
   p->lm_init_lambda_factor = 1e-9;
   p->num_threads = 0;
+  p->search = 0;
 }
 
 static int nthreads(const apdo_params* p) {
@@ -249,6 +251,170 @@ static inline float sqdist3f(float ax, float ay, float az, float bx, float by, f
   return r;
 }
 
+/* ---------------------------------------------------------------- exact kd-tree (the reference's search structure)
+ * pcl::search::KdTree wraps FLANN's KDTreeSingleIndex: an EXACT kd-tree (eps = 0) over the float xyz, L2_Simple metric.  This is a
+ * plain restatement of that idea (median split on the widest axis, leaves of <= 15 points, branch-and-bound descent); candidate
+ * distances use the same float expression as the exhaustive scan and ties are resolved on (distance, index), so both searches of
+ * this file return identical results -- the tree only makes the CPU baseline algorithmically faithful to the reference. */
+typedef struct {
+  int left, right;   /* children, -1 for leaves */
+  int begin, end;    /* point range in `order` (leaves) */
+  int axis;
+  float split;
+  float lo[3], hi[3];
+} kd_node;
+typedef struct {
+  const float* xyz;
+  int n;
+  int* order;
+  kd_node* nodes;
+  int n_nodes, cap_nodes;
+} kd_tree;
+
+static int kd_build_rec(kd_tree* t, int begin, int end) {
+  if (t->n_nodes == t->cap_nodes) {
+    t->cap_nodes = t->cap_nodes * 2 + 64;
+    t->nodes = (kd_node*)realloc(t->nodes, (size_t)t->cap_nodes * sizeof(kd_node));
+  }
+  const int id = t->n_nodes++;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int q = begin; q < end; q++) {
+    const float* p = t->xyz + 3 * (size_t)t->order[q];
+    for (int a = 0; a < 3; a++) {
+      if (p[a] < lo[a]) lo[a] = p[a];
+      if (p[a] > hi[a]) hi[a] = p[a];
+    }
+  }
+  kd_node nd;
+  nd.left = nd.right = -1;
+  nd.begin = begin;
+  nd.end = end;
+  nd.axis = 0;
+  nd.split = 0;
+  memcpy(nd.lo, lo, sizeof(lo));
+  memcpy(nd.hi, hi, sizeof(hi));
+  if (end - begin > 15) {
+    int ax = 0;
+    for (int a = 1; a < 3; a++)
+      if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+    if (hi[ax] > lo[ax]) {
+      /* median split by nth_element (quickselect) on the chosen axis */
+      int l = begin, r = end - 1;
+      const int mid = (begin + end) / 2;
+      while (l < r) {
+        const float pv = t->xyz[3 * (size_t)t->order[(l + r) / 2] + ax];
+        int i = l, j = r;
+        while (i <= j) {
+          while (t->xyz[3 * (size_t)t->order[i] + ax] < pv) i++;
+          while (t->xyz[3 * (size_t)t->order[j] + ax] > pv) j--;
+          if (i <= j) {
+            int tmp = t->order[i];
+            t->order[i] = t->order[j];
+            t->order[j] = tmp;
+            i++;
+            j--;
+          }
+        }
+        if (j < mid) l = i;
+        if (mid < i) r = j;
+      }
+      nd.axis = ax;
+      nd.split = t->xyz[3 * (size_t)t->order[mid] + ax];
+      t->nodes[id] = nd;
+      const int L = kd_build_rec(t, begin, mid);
+      const int R = kd_build_rec(t, mid, end);
+      t->nodes[id].left = L;
+      t->nodes[id].right = R;
+      return id;
+    }
+  }
+  t->nodes[id] = nd;
+  return id;
+}
+
+static kd_tree* kd_build(const float* xyz, int n) {
+  kd_tree* t = (kd_tree*)calloc(1, sizeof(kd_tree));
+  t->xyz = xyz;
+  t->n = n;
+  t->order = (int*)malloc((size_t)n * sizeof(int));
+  for (int i = 0; i < n; i++) t->order[i] = i;
+  kd_build_rec(t, 0, n);
+  return t;
+}
+static void kd_free(kd_tree* t) {
+  if (!t) return;
+  free(t->order);
+  free(t->nodes);
+  free(t);
+}
+
+/* lower bound of sqdist3(q, p) for p in the node's box: same un-fused float expression on the clamped differences => monotone */
+static inline float kd_box_bound(const kd_node* nd, const float* q) {
+  float d[3];
+  for (int a = 0; a < 3; a++) {
+    float c = q[a] < nd->lo[a] ? nd->lo[a] : (q[a] > nd->hi[a] ? nd->hi[a] : q[a]);
+    d[a] = q[a] - c;
+  }
+  float r = d[0] * d[0];
+  r = r + d[1] * d[1];
+  r = r + d[2] * d[2];
+  return r;
+}
+
+/* k best (distance, index) pairs, ascending, lexicographic ties */
+static void kd_search(const kd_tree* t, int node, const float* q, int k, float* bd, int* bi, int* cnt) {
+  const kd_node* nd = &t->nodes[node];
+  if (*cnt == k && kd_box_bound(nd, q) > bd[k - 1]) return;
+  if (nd->left < 0) {
+    for (int s = nd->begin; s < nd->end; s++) {
+      const int j = t->order[s];
+      const float d = sqdist3f(q[0], q[1], q[2], t->xyz[3 * (size_t)j], t->xyz[3 * (size_t)j + 1], t->xyz[3 * (size_t)j + 2]);
+      if (*cnt == k && !(d < bd[k - 1] || (d == bd[k - 1] && j < bi[k - 1]))) continue;
+      int pos = *cnt < k ? *cnt : k - 1;
+      while (pos > 0 && (d < bd[pos - 1] || (d == bd[pos - 1] && j < bi[pos - 1]))) {
+        bd[pos] = bd[pos - 1];
+        bi[pos] = bi[pos - 1];
+        pos--;
+      }
+      bd[pos] = d;
+      bi[pos] = j;
+      if (*cnt < k) (*cnt)++;
+    }
+    return;
+  }
+  const int first = q[nd->axis] < nd->split ? nd->left : nd->right;
+  const int second = first == nd->left ? nd->right : nd->left;
+  kd_search(t, first, q, k, bd, bi, cnt);
+  kd_search(t, second, q, k, bd, bi, cnt);
+}
+
+static kd_tree* g_align_tree = NULL; /* target tree of the align() in progress (single align at a time, like one FastAPDGICP object) */
+
+/* self k-NN through the kd-tree; identical output to apdo_knn_self */
+int apdo_knn_self_kdtree(const float* xyz, int n, int k, int* idx_out, float* sqd_out, int num_threads) {
+  if (n < k || k <= 0 || k > 64) return -1;
+  kd_tree* t = kd_build(xyz, n);
+#ifdef _OPENMP
+  int nt = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+  int nt = 1;
+#endif
+  (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(guided, 8)
+  for (int i = 0; i < n; i++) {
+    float bd[64];
+    int bi[64];
+    int cnt = 0;
+    kd_search(t, 0, xyz + 3 * (size_t)i, k, bd, bi, &cnt);
+    for (int j = 0; j < k; j++) {
+      if (idx_out) idx_out[(size_t)i * k + j] = bi[j];
+      if (sqd_out) sqd_out[(size_t)i * k + j] = bd[j];
+    }
+  }
+  kd_free(t);
+  return 0;
+}
+
 /*
  * Exact brute-force k-NN of every point in its own cloud (APD:364: kdtree.nearestKSearch(cloud->at(i), k, ...)),
  * sorted ascending by (distance, index); includes the point itself.  idx_out: n*k int32, sqd_out: n*k float
@@ -371,7 +537,7 @@ int apdo_calculate_covariances(const float* xyz, int n, const apdo_params* p, do
   int k = p->k_correspondences;
   int* idx = (int*)malloc((size_t)n * k * sizeof(int));
   if (!idx) return -3;
-  int rc = apdo_knn_self(xyz, n, k, idx, NULL, p->num_threads);
+  int rc = p->search == 1 ? apdo_knn_self_kdtree(xyz, n, k, idx, NULL, p->num_threads) : apdo_knn_self(xyz, n, k, idx, NULL, p->num_threads);
   if (rc == 0) rc = apdo_covariances_from_knn(xyz, n, idx, k, p->regularization, cov_out, p->num_threads);
   free(idx);
   return rc;
@@ -424,17 +590,25 @@ int apdo_update_correspondences(const double* T, const float* src_xyz, int n, co
   int nt = nthreads(p);
   (void)nt;
   const double thr2 = p->corr_dist_threshold * p->corr_dist_threshold;
+  /* the reference builds the target tree once in setInputTarget (APD:132); apdo_align does the same and lends it through g_align_tree */
+  const int borrowed = (p->search == 1 && g_align_tree && g_align_tree->xyz == tgt_xyz && g_align_tree->n == m);
+  kd_tree* tree = borrowed ? g_align_tree : ((p->search == 1 && m > 0) ? kd_build(tgt_xyz, m) : NULL);
 #pragma omp parallel for num_threads(nt) schedule(guided, 8)
   for (int i = 0; i < n; i++) {
     float q[3];
     transform_point_f(Tf, src_xyz[3 * i], src_xyz[3 * i + 1], src_xyz[3 * i + 2], q); /* APD:176 */
     float best = INFINITY;
     int bj = -1;
-    for (int j = 0; j < m; j++) { /* APD:178 */
-      float d = sqdist3f(q[0], q[1], q[2], tgt_xyz[3 * j], tgt_xyz[3 * j + 1], tgt_xyz[3 * j + 2]);
-      if (d < best) {
-        best = d;
-        bj = j;
+    if (tree) {
+      int cnt = 0;
+      kd_search(tree, 0, q, 1, &best, &bj, &cnt);
+    } else {
+      for (int j = 0; j < m; j++) { /* APD:178 */
+        float d = sqdist3f(q[0], q[1], q[2], tgt_xyz[3 * j], tgt_xyz[3 * j + 1], tgt_xyz[3 * j + 2]);
+        if (d < best) {
+          best = d;
+          bj = j;
+        }
       }
     }
     sqd[i] = best;                                  /* APD:180 */
@@ -465,6 +639,7 @@ int apdo_update_correspondences(const double* T, const float* src_xyz, int n, co
     }
     M[15] = 0.0; /* APD:218 */
   }
+  if (!borrowed) kd_free(tree);
   return 0;
 }
 
@@ -729,6 +904,7 @@ int apdo_align(const float* guess, const float* src_xyz, const float* src_label,
   if (!corr || !sqd || !maha || !geo_w) return -3;
   apdo_geo_weights(src_cov, n, geo_w);
   apdo_counters cnt = {0, 0};
+  if (p->search == 1 && m > 0) g_align_tree = kd_build(tgt_xyz, m);
 
   for (int it = 0; it < p->max_iterations && !converged; it++) { /* LSQ:67 */
     nr_iterations = it;                                           /* LSQ:68 */
@@ -790,6 +966,8 @@ int apdo_align(const float* guess, const float* src_xyz, const float* src_label,
   if (converged_out) *converged_out = converged;
   if (nr_iterations_out) *nr_iterations_out = nr_iterations;
   if (counters) *counters = cnt;
+  kd_free(g_align_tree);
+  g_align_tree = NULL;
   free(corr);
   free(sqd);
   free(maha);

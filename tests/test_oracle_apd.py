@@ -187,3 +187,23 @@ def test_lm_bookkeeping(oracle_apd):
 def test_too_few_points_rejected(oracle_apd):
     with pytest.raises(ValueError):
         oracle_apd.knn_self(np.zeros((5, 3), np.float32), 20)
+
+
+def test_kdtree_search_equals_exhaustive(oracle_apd):
+    """The oracle's kd-tree path (the CPU baseline, algorithmically what pcl::search::KdTree does) returns exactly what its
+    exhaustive scan returns: same k-NN lists, same correspondences, same align."""
+    sx, sl, tx, tl, _ = synth.scan_pair(3000, 3300, seed=31)
+    i0, d0 = oracle_apd.knn_self(sx, 20)
+    i1, d1 = oracle_apd.knn_self(sx, 20, kdtree=True)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    gx, gy = np.meshgrid(np.arange(15, dtype=np.float32), np.arange(15, dtype=np.float32))
+    lattice = np.concatenate([np.stack([gx.ravel(), gy.ravel(), np.zeros(225, np.float32)], axis=1)] * 2)  # ties + duplicates
+    a, _ = oracle_apd.knn_self(lattice, 20)
+    b, _ = oracle_apd.knn_self(lattice, 20, kdtree=True)
+    assert np.array_equal(a, b)
+    pb, pk = oracle_apd.launch_params(), oracle_apd.launch_params(search=1)
+    cs, ct = oracle_apd.calculate_covariances(sx, pk), oracle_apd.calculate_covariances(tx, pk)
+    assert np.array_equal(cs, oracle_apd.calculate_covariances(sx, pb))
+    rb = oracle_apd.align(np.eye(4), sx, sl, tx, tl, cs, ct, pb)
+    rk = oracle_apd.align(np.eye(4), sx, sl, tx, tl, cs, ct, pk)
+    assert np.array_equal(rb["T"], rk["T"]) and rb["n_linearize"] == rk["n_linearize"]
