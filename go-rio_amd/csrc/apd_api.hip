@@ -376,7 +376,7 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     if (chunk < 256) chunk = 256;
     const int s = pruned ? 1 : (c.n_pad + chunk - 1) / chunk;
     if (s > max_splits) max_splits = s;
-    const size_t need = (size_t)s * K * c.n;
+    const size_t need = pruned ? 0 : (size_t)s * K * c.n;
     if (need > c.part_cap) {
       hipFree(c.part_d); hipFree(c.part_i);
       c.part_d = nullptr; c.part_i = nullptr;
@@ -414,12 +414,16 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     dim3 gp((roundup(max_n, 512) + 255) / 256, 1, njobs);
     if (K == 20) {
       if (pruned) knn_pruned_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
-      else knn_partial_kernel<20><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
-      cov_finalize_kernel<20><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
+      else {
+        knn_partial_kernel<20><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
+        cov_finalize_kernel<20><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
+      }
     } else {
       if (pruned) knn_pruned_kernel<32><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
-      else knn_partial_kernel<32><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
-      cov_finalize_kernel<32><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
+      else {
+        knn_partial_kernel<32><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
+        cov_finalize_kernel<32><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
+      }
     }
   }
   HIP_TRY(lead, hipGetLastError());

@@ -357,8 +357,8 @@ __device__ __forceinline__ void topk_insert_lex(float (&bd)[K], int (&bi)[K], fl
   }
 }
 
-// self k-NN, pruned.  Writes the final sorted list of every point to part_d / part_i in the [split = 0][t][orig index] layout that
-// cov_finalize_kernel reads.  grid: (ceil(n_spad / 256), 1, clouds), block 256.
+// self k-NN, pruned, fused with the covariance estimation of APD:366-407 (covariance_from_list).
+// grid: (ceil(n_spad / 256), 1, clouds), block 256.
 template <int K>
 __global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restrict__ jobs) {
   const KnnJob& job = jobs[blockIdx.z];
@@ -425,14 +425,7 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restric
       }
     }
   }
-  if (p < n) {
-    const size_t base = (size_t)si.orig[p];
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-      job.part_d[base + (size_t)t * n] = bd[t];
-      job.part_i[base + (size_t)t * n] = bi[t];
-    }
-  }
+  if (p < n) covariance_from_list<K>(job, si.orig[p], bd, bi);  // lists never leave the registers: no partial lists, no second kernel
 }
 
 }  // namespace gorio

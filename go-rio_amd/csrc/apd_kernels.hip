@@ -223,30 +223,12 @@ __device__ __forceinline__ void inv_sym3(double a00, double a01, double a02, dou
   i22 = (a00 * a11 - a01 * a01) * r;
 }
 
-// grid: (ceil(n/256), 1, clouds).  Merges the per-split lists, then APD:366-407 per point.
+// APD:366-407 for one point from its final neighbour list (bd, bi sorted by distance then index): 3x3 covariance in fp64 in the
+// list order (bit-identical sums to the host restatement), regularisation, geo weight; results stored at original index i.
 template <int K>
-__global__ __launch_bounds__(256) void cov_finalize_kernel(const KnnJob* __restrict__ jobs) {
-  const KnnJob job = jobs[blockIdx.z];
-  const int n = job.cloud.n;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void covariance_from_list(const KnnJob& job, int i, const float (&bd)[K], const int (&bi)[K]) {
   const int k = job.k;
-  float bd[K];
-  int bi[K];
-#pragma unroll
-  for (int t = 0; t < K; ++t) {
-    bd[t] = INFINITY;
-    bi[t] = 0x7fffffff;
-  }
-  // splits ascend in index range and each list is sorted by (distance, index): strict '<' insertion keeps (d, idx) order
-  for (int s = 0; s < job.splits; ++s) {
-    const size_t base = (size_t)s * K * n + i;
-    for (int t = 0; t < K; ++t) {
-      const float d = job.part_d[base + (size_t)t * n];
-      if (!(d < bd[K - 1])) break;  // the rest of this list is no better
-      topk_insert<K>(bd, bi, d, job.part_i[base + (size_t)t * n]);
-    }
-  }
+  (void)bd;
   if (job.knn_out) {
 #pragma unroll
     for (int t = 0; t < K; ++t)
@@ -312,6 +294,33 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(const KnnJob* __restr
   double* o = job.cloud.cov6 + (size_t)i * 6;
   o[0] = r00; o[1] = r01; o[2] = r02; o[3] = r11; o[4] = r12; o[5] = r22;
   job.cloud.geo_w[i] = geo_weight(r00, r01, r02, r11, r12, r22);
+}
+
+// grid: (ceil(n/256), 1, clouds).  Merges the per-split lists, then APD:366-407 per point.
+template <int K>
+__global__ __launch_bounds__(256) void cov_finalize_kernel(const KnnJob* __restrict__ jobs) {
+  const KnnJob job = jobs[blockIdx.z];
+  const int n = job.cloud.n;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = job.k;
+  float bd[K];
+  int bi[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    bd[t] = INFINITY;
+    bi[t] = 0x7fffffff;
+  }
+  // splits ascend in index range and each list is sorted by (distance, index): strict '<' insertion keeps (d, idx) order
+  for (int s = 0; s < job.splits; ++s) {
+    const size_t base = (size_t)s * K * n + i;
+    for (int t = 0; t < K; ++t) {
+      const float d = job.part_d[base + (size_t)t * n];
+      if (!(d < bd[K - 1])) break;  // the rest of this list is no better
+      topk_insert<K>(bd, bi, d, job.part_i[base + (size_t)t * n]);
+    }
+  }
+  covariance_from_list<K>(job, i, bd, bi);
 }
 
 // geo weights for covariances supplied through setSourceCovariances / setTargetCovariances

@@ -331,7 +331,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 2);
       ug::ata_kernel<<<dim3(tiles_n, tiles_n, nw), 256, 0, c.stream>>>(c.d_wins, problem);
       for (int it = 0; it <= 51; ++it) {
-        ug::lm_step_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
+        ug::lm_step_kernel<<<nw, 512, 0, c.stream>>>(c.d_wins);
         if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
         else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
         ug::lm_decide_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);

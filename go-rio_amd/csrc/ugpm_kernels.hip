@@ -461,25 +461,37 @@ __device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, in
       if (c <= r) L.D[r][c] = A[(size_t)(kb + r) * lda + kb + c];
     }
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {  // unblocked factorisation of the diagonal block in LDS
-      const double ajj = L.D[j][j];
-      __syncthreads();
-      if (!(ajj > 0.0)) {
-        if (threadIdx.x == 0) *sflag = 1;
-        __syncthreads();
-        return false;
+    // factorisation of the 16 x 16 diagonal block by ONE wave (lane r owns row r): only wave-level ordering is needed between
+    // the steps, so the 16 columns cost no workgroup barrier
+    if (threadIdx.x < 64) {
+      const int r = threadIdx.x;
+      bool ok = true;
+      for (int j = 0; j < nb; ++j) {
+        const double ajj = L.D[j][j];
+        if (!(ajj > 0.0)) {
+          ok = false;
+          break;
+        }
+        const double d = sqrt(ajj);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (r == j) L.D[j][j] = d;
+        if (r > j && r < nb) L.D[r][j] /= d;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (r > j && r < nb) {
+          const double lrj = L.D[r][j];
+          for (int c = j + 1; c <= r; ++c) L.D[r][c] -= lrj * L.D[c][j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      const double d = sqrt(ajj);
-      if (threadIdx.x == 0) L.D[j][j] = d;
-      for (int r = j + 1 + threadIdx.x; r < nb; r += blockDim.x) L.D[r][j] /= d;
-      __syncthreads();
-      const int m2 = nb - j - 1;
-      for (int q = threadIdx.x; q < m2 * m2; q += blockDim.x) {
-        const int r = j + 1 + q / m2, c = j + 1 + q % m2;
-        if (c <= r) L.D[r][c] -= L.D[r][j] * L.D[c][j];
-      }
-      __syncthreads();
+      if (!ok && threadIdx.x == 0) *sflag = 1;
     }
+    __syncthreads();
+    if (*sflag) return false;
     for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
       const int r = q / nb, c = q % nb;
       if (c <= r) A[(size_t)(kb + r) * lda + kb + c] = L.D[r][c];
@@ -1054,7 +1066,7 @@ __global__ __launch_bounds__(256) void lm_begin_kernel(const UgpmWin* __restrict
 
 // One trust-region step: (on fresh J^T J) cost / gradient test / Jacobi scaling, then solve (D J^T J D + diag / radius) y = D g,
 // step = -y, delta = D step, model cost change, candidate x_new.  grid: (windows), block 256.
-__global__ __launch_bounds__(256) void lm_step_kernel(const UgpmWin* __restrict__ wins) {
+__global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin& w = wins[blockIdx.x];
   if (*w.status != 0 || w.lmi[1]) return;
   const int n = 3 * w.S;
