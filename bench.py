@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--search", default="pruned", choices=["brute", "pruned"], help="correspondence / k-NN search: both are exact and return identical indices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the GP windows after the scan matching instead of beside it")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL) in production; gloo only to rehearse the N > 1 path on one GPU")
+    ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="rehearsal only: put every rank on this device instead of LOCAL_RANK")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1)
     return ap.parse_args()
 
@@ -55,16 +57,20 @@ def main():
     import torch
 
     dist = None
+    if args.all_ranks_on_device >= 0:
+        local_rank = args.all_ranks_on_device
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the two tiny reduction tensors live
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     gorio = importlib.import_module("go-rio_amd")
     synth = gorio.synth
@@ -168,10 +174,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cnt = torch.tensor([units, wins], dtype=torch.float64, device=dev)
+        cnt = torch.tensor([units, wins], dtype=torch.float64, device=red_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         units, wins = int(cnt[0].item()), int(cnt[1].item())
 

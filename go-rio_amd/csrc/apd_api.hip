@@ -442,7 +442,11 @@ float gate_bound(double thr2) {
 void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_spad, int count) {
   if (lead->params.search == GORIO_SEARCH_PRUNED) {
     const double thr = lead->params.corr_dist_threshold;
-    nn_search_pruned_kernel<<<dim3((max_src_spad + 255) / 256, 1, count), 256, 0, lead->stream>>>(d_desc, gate_bound(thr * thr));
+    const long waves = (long)count * ((max_src_spad + 63) / 64);
+    int splits = (int)(4096 / (waves > 0 ? waves : 1));  // a lone 16k scan has 256 query waves: deal the tile groups over more workgroups
+    if (splits < 1) splits = 1;
+    if (splits > 16) splits = 16;
+    nn_search_pruned_kernel<<<dim3((max_src_spad + 255) / 256, splits, count), 256, 0, lead->stream>>>(d_desc, gate_bound(thr * thr));
   } else {
     nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(d_desc);
   }

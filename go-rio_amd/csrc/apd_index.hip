@@ -279,7 +279,7 @@ __device__ __forceinline__ float lane_f(float v, int lane) { return __uint_as_fl
 // visit order: 64-tile groups outward from `g0` (where near neighbours are expected) so the bound tightens early.
 
 // 1-NN of every source point in the target, pruned.  One lane = one source point taken in MORTON order (a wave's 64 queries are
-// spatially compact).  grid: (ceil(n_spad_src / 256), 1, pairs), block 256.
+// spatially compact).  grid: (ceil(n_spad_src / 256), splits, pairs), block 256.
 // Output: best_key[orig source index] = (float bits of d) << 32 | orig target index, exactly as nn_search_kernel.
 __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* __restrict__ descs, float bound_f) {
   const PairDesc& pd = descs[blockIdx.z];
@@ -306,10 +306,12 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   const int ng = (ti.n_tiles + 63) / 64;
   int g0 = (int)(((long)(blockIdx.x * 256 + (threadIdx.x & ~63)) * ng) / (si.n > 0 ? si.n : 1));
   g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);
+  const int nsplit = gridDim.y;  // > 1 only when a launch has too few query waves to fill the chip: tile groups are dealt round-robin
   for (int v = 0; v < 2 * ng; ++v) {
     const int off = (v + 1) >> 1;
     const int g = (v & 1) ? g0 - off : g0 + off;
     if (g < 0 || g >= ng) continue;
+    if (nsplit > 1 && (g % nsplit) != (int)blockIdx.y) continue;
     const int tl = g * 64 + lane;
     float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
     if (tl < ti.n_tiles) {
@@ -338,7 +340,10 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
       bestd = __uint_as_float((unsigned int)(best >> 32));
     }
   }
-  if (p < si.n && (unsigned int)best != 0xffffffffu) pd.best_key[si.orig[p]] = best;
+  if (p < si.n && (unsigned int)best != 0xffffffffu) {
+    if (nsplit > 1) atomicMin(pd.best_key + si.orig[p], best);
+    else pd.best_key[si.orig[p]] = best;
+  }
 }
 
 // lexicographic (distance, original index) insertion into an ascending register list
