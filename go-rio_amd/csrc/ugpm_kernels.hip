@@ -25,6 +25,18 @@
 namespace gorio {
 namespace ug {
 
+// The window descriptors are written by the host before the launch and never change during it: reading one through the
+// CONSTANT address space puts its members in SGPRs (s_load) and, more importantly, lets the compiler treat every pointer member
+// as a GLOBAL pointer (a generic pointer loaded from constant memory cannot point to LDS / scratch), so all accesses below are
+// global_load / global_store instead of flat_* -- flat operations count against both the LDS and the vector-memory wait
+// counters and serialise the two.
+__device__ __forceinline__ UgpmWin load_win(const UgpmWin* __restrict__ wins, int i) {
+  UgpmWin w;
+  __builtin_memcpy(&w, (const __attribute__((address_space(4))) void*)(wins + i), sizeof(UgpmWin));
+  return w;
+}
+
+
 constexpr double kDt = 0.01;        // kNumDtJacobianDelta, math_utils.h:15
 constexpr double kBw = 0.0001;      // kNumGyrBiasJacobianDelta, math_utils.h:17
 constexpr double kExpTol = 1e-14;   // kExpNormTolerance, math_utils.h:11
@@ -295,6 +307,194 @@ __device__ void lpm_rotation(const UgpmWin& w, int variant) {
   }
 }
 
+// ---- workgroup-parallel form of lpm_rotation (same result up to the association order of the rotation products) ----
+// The merged time line is materialised in LDS by RANK (every stamp finds its position with binary searches in the other
+// lists), the interpolated rates and the per-step rotations are evaluated by all lanes, and the running product -- the only
+// sequential part of the reference loop -- becomes a three-phase scan: per-lane chunk products, a Hillis-Steele scan of the
+// chunk totals in LDS, and a final sweep.  kLpmMaxT bounds the line length; longer lines use the one-lane routine above.
+constexpr int kLpmMaxT = 2048;
+struct LpmLds {
+  double tl[kLpmMaxT];             // merged stamps
+  unsigned short kind[kLpmMaxT];   // list id of the stamp
+  unsigned short kidx[kLpmMaxT];   // its index in that list
+  double tot[2][256][9];           // chunk totals, ping-pong
+  double ps[9];                    // P(start index)^T
+  int start_rank;
+};
+
+__device__ __forceinline__ int lower_bound_f(int n, double v, const double* __restrict__ a, double shift) {  // first i with a[i] - shift >= v
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] - shift < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ int upper_bound_f(int n, double v, const double* __restrict__ a, double shift) {  // first i with a[i] - shift > v
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] - shift <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// returns false (nothing written) when the time line does not fit kLpmMaxT.  All threads of the workgroup must call it.
+__device__ bool lpm_rotation_parallel(const UgpmWin& w, int variant, LpmLds& L, double* __restrict__ Rseq /* [T][9] global scratch */, size_t rseq_cap) {
+  const int S = w.S, G = w.G, V = w.V;
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  const double lpm_start = w.state_t[0];
+  const double tshift = variant == 1 ? kDt : 0.0;
+  // list sizes and the 500 Hz filler (same rule as lpm_rotation)
+  int nfake = 0;
+  double fake_first = 0.0, fake_q = 0.0;
+  {
+    double first = w.state_t[0], top1 = -1e300, top2 = -1e300;
+    auto consider = [&](double c) {
+      if (c > top1) { top2 = top1; top1 = c; } else if (c > top2) { top2 = c; }
+    };
+    consider(w.state_t[S - 1]); if (S > 1) consider(w.state_t[S - 2]);
+    consider(w.state_t[S - 1] + kDt); if (S > 1) consider(w.state_t[S - 2] + kDt);
+    consider(w.start_t);
+    consider(lpm_start + kDt); consider(lpm_start);
+    consider(w.vel_t[V - 1] - tshift); if (V > 1) consider(w.vel_t[V - 2] - tshift);
+    first = fmin(first, fmin(w.start_t, w.vel_t[0] - tshift));
+    if ((top1 - top2) > (1.0 / 500.0)) {
+      const int nb = (int)floor((top1 - first) * 500.0);
+      if (nb > 0) { nfake = nb; fake_first = first; fake_q = (top1 - first) / ((double)nb); }
+    }
+  }
+  const int T = 2 * S + 3 + V + nfake;
+  if (T > kLpmMaxT || (size_t)T * 9 > rseq_cap) return false;
+  // ---- 1. rank of every stamp.  tie order of the lists: 3, 0, 1, 2, 4, 5  (prio[l] below)
+  auto count_in = [&](int l, double v, bool upper) -> int {  // number of stamps of list l that precede a stamp of value v
+    switch (l) {
+      case 0: return upper ? upper_bound_f(S, v, w.state_t, 0.0) : lower_bound_f(S, v, w.state_t, 0.0);
+      case 1: return upper ? upper_bound_f(S, v, w.state_t, -kDt) : lower_bound_f(S, v, w.state_t, -kDt);
+      case 2: return upper ? (w.start_t <= v ? 1 : 0) : (w.start_t < v ? 1 : 0);
+      case 3: { const double a0 = lpm_start, a1 = lpm_start + kDt; return upper ? ((a0 <= v) + (a1 <= v)) : ((a0 < v) + (a1 < v)); }
+      case 4: return upper ? upper_bound_f(V, v, w.vel_t, tshift) : lower_bound_f(V, v, w.vel_t, tshift);
+      default: {
+        int lo = 0, hi = nfake;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const double c = fake_first + mid * fake_q;
+          if (upper ? (c <= v) : (c < v)) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+      }
+    }
+  };
+  const int prio[6] = {1, 2, 3, 0, 4, 5};
+  const int nl[6] = {S, S, 1, 2, V, nfake};
+  for (int e = tid; e < T; e += nthr) {
+    int l = 0, i = e;
+    while (i >= nl[l]) { i -= nl[l]; ++l; }
+    double v;
+    switch (l) {
+      case 0: v = w.state_t[i]; break;
+      case 1: v = w.state_t[i] + kDt; break;
+      case 2: v = w.start_t; break;
+      case 3: v = lpm_start + (i ? kDt : 0.0); break;
+      case 4: v = w.vel_t[i] - tshift; break;
+      default: v = fake_first + i * fake_q; break;
+    }
+    int rank = i;
+    for (int b = 0; b < 6; ++b)
+      if (b != l && nl[b] > 0) rank += count_in(b, v, prio[b] < prio[l]);
+    L.tl[rank] = v;
+    L.kind[rank] = (unsigned short)l;
+    L.kidx[rank] = (unsigned short)i;
+    if (l == 3 && i == 0) L.start_rank = rank;
+  }
+  __syncthreads();
+  // ---- 2./3. interpolated rate at every stamp and the step rotation E_i = Exp(w_i (t_{i+1} - t_i)), i < T - 1, chunked per lane
+  auto gt = [&](int i) -> double { return w.gyr_t[i] - tshift; };
+  auto gd = [&](int a, int i) -> double {
+    double d = w.gyr[a * G + i];
+    if (variant == 0) d -= w.gyr_bias[a];
+    if (variant - 2 == a) d += kBw;
+    return d;
+  };
+  const double gt0 = gt(0);
+  auto step_rot = [&](int i) -> M3 {
+    const double t = L.tl[i];
+    int p = 0;
+    if (t > gt0) {
+      p = lower_bound_f(G, t, w.gyr_t, tshift) - 1;  // gt[p] < t <= gt[p + 1]
+      if (p > G - 2) p = G - 2;
+      if (p < 0) p = 0;
+    }
+    const double t0 = gt(p), t1 = gt(p + 1);
+    double wv[3];
+    for (int a = 0; a < 3; ++a) {
+      const double d0 = gd(a, p), d1 = gd(a, p + 1);
+      const double al = (d1 - d0) / (t1 - t0);
+      const double be = d0 - (al * t0);
+      wv[a] = al * t + be;
+    }
+    const double dt = L.tl[i + 1] - t;
+    return expMap(v3(wv[0] * dt, wv[1] * dt, wv[2] * dt));
+  };
+  // P(i) = E_0 E_1 ... E_{i-1} (P(0) = I).  Lane c owns stamps [c*ch, (c+1)*ch): phase A = local products
+  const int nch = nthr < 256 ? nthr : 256;
+  const int ch = (T + nch - 1) / nch;
+  if (tid < nch) {
+    M3 acc = eye3();
+    const int i0 = tid * ch, i1 = min(T, i0 + ch);
+    for (int i = i0; i < i1; ++i) {
+      storeM(Rseq + (size_t)i * 9, acc);            // local prefix (exclusive)
+      if (i < T - 1) acc = mmul(acc, step_rot(i));
+    }
+    storeM(&L.tot[0][tid][0], acc);  // product of the chunk's steps
+  }
+  __syncthreads();
+  // phase B: inclusive Hillis-Steele scan of the chunk totals
+  int cur = 0;
+  for (int off = 1; off < nch; off <<= 1) {
+    if (tid < nch) {
+      M3 m = loadM(&L.tot[cur][tid][0]);
+      if (tid >= off) m = mmul(loadM(&L.tot[cur][tid - off][0]), m);
+      storeM(&L.tot[cur ^ 1][tid][0], m);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // phase C: P(i) = (product of all earlier chunks) * local prefix; P(start) for the re-referencing of preint.h:477-485
+  if (tid < nch) {
+    const M3 pre = tid > 0 ? loadM(&L.tot[cur][tid - 1][0]) : eye3();
+    const int i0 = tid * ch, i1 = min(T, i0 + ch);
+    for (int i = i0; i < i1; ++i) {
+      const M3 Pi = mmul(pre, loadM(Rseq + (size_t)i * 9));
+      storeM(Rseq + (size_t)i * 9, Pi);
+      if (i == L.start_rank) storeM(L.ps, mtr(Pi));
+    }
+  }
+  __syncthreads();
+  // ---- 4./5. re-reference to the LPM start and capture the stamps UGPM reads
+  const M3 PsT = loadM(L.ps);
+  double* Rq = w.Rq + (size_t)variant * 2 * S * 9;
+  for (int i = tid; i < T; i += nthr) {
+    const int l = L.kind[i], idx = L.kidx[i];
+    if (l == 5 || l == 3) continue;
+    if (l == 4 && variant != 0) continue;
+    // stamps ahead of the LPM start keep the un-referenced product, as the sequential loop leaves them
+    const M3 Pi = loadM(Rseq + (size_t)i * 9);
+    const M3 R = i >= L.start_rank ? mmul(PsT, Pi) : Pi;
+    if (l == 0) storeM(Rq + (size_t)idx * 9, R);
+    else if (l == 1) storeM(Rq + (size_t)(S + idx) * 9, R);
+    else if (l == 2) storeM(w.Rstart + variant * 9, R);
+    else {  // reprojectVelData, math_utils.h:415-426
+      const V3 vr = mvec(R, v3(w.vel[idx] - w.vel_bias[0], w.vel[V + idx] - w.vel_bias[1], w.vel[2 * V + idx] - w.vel_bias[2]));
+      w.velr[idx] = vr.x;
+      w.velr[V + idx] = vr.y;
+      w.velr[2 * V + idx] = vr.z;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
 // Trapezoid position integration of the rotated velocity (posePreintLPM main loop, preint.h:552-665, values only) for one axis.
 __device__ void lpm_position(const UgpmWin& w, int axis) {
   const int S = w.S, V = w.V;
@@ -386,11 +586,21 @@ __device__ void unwrap_variant(const UgpmWin& w, int variant) {
 
 // grid: (windows), block 320 = 5 waves; wave v's first lane integrates LPM variant v.
 __global__ __launch_bounds__(320) void lpm_init_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0) return;
   const int v = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int S = w.S;
-  if (lane == 0) lpm_rotation(w, v);
+  __shared__ LpmLds lds;
+  {
+    // scratch for the P(i) sequence: the (still unused) rotation-problem Jacobian buffer
+    double* Rseq = w.Jrot;
+    const size_t cap = (size_t)(3 * w.S + 3 * w.G) * 3 * w.S;
+    bool par_ok = true;
+    for (int var = 0; var < 5 && par_ok; ++var) par_ok = lpm_rotation_parallel(w, var, lds, Rseq, cap);
+    if (!par_ok) {  // time line too long for the LDS form: one lane per integration
+      if (lane == 0) lpm_rotation(w, v);
+    }
+  }
   __syncthreads();
   if (v == 0 && lane < 3) lpm_position(w, lane);
   if (lane == 0) unwrap_variant(w, v);
@@ -439,125 +649,228 @@ __global__ __launch_bounds__(320) void lpm_init_kernel(const UgpmWin* __restrict
 // =============================================================================================== block-wide dense helpers
 
 // In-place lower Cholesky of the n x n matrix A (row-major, leading dimension lda, resident in HBM / L2) by one workgroup.
-// Right-looking, blocked by 16 columns: the 16 x 16 diagonal block is factored in LDS, the panel below is solved against it one
-// row per lane and kept in LDS, and the trailing update A22 -= P P^T runs as 4 x 4 register tiles fed from LDS -- the only
-// global traffic is one read-modify-write sweep of the trailing triangle per block column.  Returns false on a non-positive
-// pivot.  The upper triangle is never referenced.  n <= kCholMaxN.
+// Right-looking, blocked by 16 columns:
+//  - the 16 x 16 diagonal block is factored by one wave entirely in REGISTERS (lane r owns row r; the pivot column is exchanged
+//    with v_readlane, whose lane operand is a compile-time constant after unrolling -- no LDS round trip inside the 16 steps);
+//  - the panel below is solved against it one row per lane (its 16 entries are requested from L2 before the factor finishes) and
+//    kept in LDS;
+//  - the trailing update A22 -= P P^T runs on the fp64 matrix cores, one 16 x 16 tile per MFMA chain, operands read from the LDS
+//    panel; the only global traffic is one read-modify-write sweep of the trailing triangle per block column.
+// Returns false on a non-positive pivot.  The upper triangle is never referenced.  n <= kCholMaxN.
+// With `rhs` (n doubles in GLOBAL memory like A; needs n < 384) the right-hand side rides along as one more row of the matrix being factored, so on
+// return it holds L^-1 rhs: the forward substitution costs nothing beyond one extra row in every panel.
 constexpr int kCholNB = 16;
 constexpr int kCholMaxN = 6 * 160;
+#ifdef GORIO_CHOL_TIMING  // tools/chol_bench.hip: cycles per phase, accumulated by thread 0 of workgroup 0
+__device__ long long g_chol_t[12];
+#define CHOL_T(k)                                                         \
+  do {                                                                    \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                            \
+      const long long now_ = (long long)__builtin_readcyclecounter();     \
+      g_chol_t[k] += now_ - chol_t_last_;                                 \
+      chol_t_last_ = now_;                                                \
+    }                                                                     \
+  } while (0)
+#define CHOL_T_INIT long long chol_t_last_ = (long long)__builtin_readcyclecounter()
+#define CHOL_T_VMWAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define CHOL_T(k) do { } while (0)
+#define CHOL_T_INIT do { } while (0)
+#define CHOL_T_VMWAIT do { } while (0)
+#endif
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 struct CholLds {
   double D[kCholNB][kCholNB + 1];
+  double Dinv[kCholNB];
+  double dinv_n[384];        // 1 / L[i][i] of every row, kept for block_backward (filled when a right-hand side is carried)
+  unsigned short tile[328];  // q -> (tile row << 8 | tile column) of the lower-triangular 16 x 16 tiling, q = tr (tr + 1) / 2 + tc, tr < 25
   double P[kCholMaxN > 384 ? 384 : kCholMaxN][kCholNB + 1];  // panel rows of the current block column (n - kb - NB <= 384 rows handled per pass)
 };
 
-__device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, int lda, CholLds& L, int* __restrict__ sflag) {
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1 / sqrt(a) to about 1 ulp: hardware estimate + two Newton steps (each y += y (1/2 - a/2 y^2)).  The pivot of the block
+// factorisation needs sqrt(a) and 1 / sqrt(a) on its critical path; this chain is a quarter of the length of sqrt + divide.
+__device__ __forceinline__ double rsqrt_newton(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  const double h = 0.5 * a;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {  // v_rsq_f64 is good to 2^-23: two quadratic steps reach double precision
+    const double e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+  }
+  return y;
+}
+
+__device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, int lda, CholLds& L, int* __restrict__ sflag, double* __restrict__ rhs = nullptr) {
   constexpr int NB = kCholNB;
-  if (threadIdx.x == 0) *sflag = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)(blockDim.x >> 6);
+  if (tid == 0) *sflag = 0;
+  for (int q = tid; q < 325; q += blockDim.x) {
+    int tr = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+    while (tr * (tr + 1) / 2 > q) --tr;
+    while ((tr + 1) * (tr + 2) / 2 <= q) ++tr;
+    L.tile[q] = (unsigned short)((tr << 8) | (q - tr * (tr + 1) / 2));
+  }
   __syncthreads();
+  CHOL_T_INIT;
   for (int kb = 0; kb < n; kb += NB) {
     const int nb = min(NB, n - kb);
-    for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
-      const int r = q / nb, c = q % nb;
-      if (c <= r) L.D[r][c] = A[(size_t)(kb + r) * lda + kb + c];
-    }
-    __syncthreads();
-    // factorisation of the 16 x 16 diagonal block by ONE wave (lane r owns row r): only wave-level ordering is needed between
-    // the steps, so the 16 columns cost no workgroup barrier
-    if (threadIdx.x < 64) {
-      const int r = threadIdx.x;
-      bool ok = true;
-      for (int j = 0; j < nb; ++j) {
-        const double ajj = L.D[j][j];
-        if (!(ajj > 0.0)) {
-          ok = false;
-          break;
-        }
-        const double d = sqrt(ajj);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (r == j) L.D[j][j] = d;
-        if (r > j && r < nb) L.D[r][j] /= d;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (r > j && r < nb) {
-          const double lrj = L.D[r][j];
-          for (int c = j + 1; c <= r; ++c) L.D[r][c] -= lrj * L.D[c][j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-      if (!ok && threadIdx.x == 0) *sflag = 1;
-    }
-    __syncthreads();
-    if (*sflag) return false;
-    for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
-      const int r = q / nb, c = q % nb;
-      if (c <= r) A[(size_t)(kb + r) * lda + kb + c] = L.D[r][c];
-    }
     const int m = n - kb - nb;  // rows below the diagonal block
-    if (m <= 0) break;
-    for (int p0 = 0; p0 < m; p0 += 384) {  // panel passes (one pass unless n > 400)
-      const int mp = min(384, m - p0);
-      for (int i = threadIdx.x; i < mp; i += blockDim.x) {  // panel solve: row i of L21 = A21 L11^-T
-        double* arow = A + (size_t)(kb + nb + p0 + i) * lda + kb;
-        double x[NB];
+    const int me = m + (rhs != nullptr ? 1 : 0);
+    auto panel_row = [&](int i) -> double* { return (rhs != nullptr && i == m) ? rhs + kb : A + (size_t)(kb + nb + i) * lda + kb; };
+    double x[NB];
+    const bool own = tid < min(me, 384);
+    auto load_row = [&](const double* arow) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
-          if (c < nb) {
-            double v = arow[c];
+      for (int c = 0; c < NB; ++c) x[c] = c < nb ? arow[c] : 0.0;
+    };
+    // waves that do not factor request their first panel row now: it does not depend on the factor
+    if (wave != 0 && own) load_row(panel_row(tid));
+    if (wave == 0) {  // diagonal block, lane r = row r, in registers.  A short last block is padded with identity rows.
+      const int r = lane;
+      double a[NB];
 #pragma unroll
-            for (int q = 0; q < NB; ++q)
-              if (q < c) v -= x[q] * L.D[c][q];
-            v /= L.D[c][c];
-            x[c] = v;
-            arow[c] = v;
-            L.P[i][c] = v;
-          } else {
-            x[c] = 0.0;
-            L.P[i][c] = 0.0;
-          }
+      for (int c = 0; c < NB; ++c) a[c] = (r < nb && c <= r) ? A[(size_t)(kb + r) * lda + kb + c] : ((r == c) ? 1.0 : 0.0);
+      CHOL_T_VMWAIT;
+      CHOL_T(8);
+      bool ok = true;
+      double yinv = 1.0;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const double ajj = readlane_f64(a[j], j);
+        if (!(ajj > 0.0)) ok = false;
+        const double y = rsqrt_newton(ajj);
+        const double lrj = a[j] * y;  // row j: a_jj / sqrt(a_jj) = sqrt(a_jj)
+        if (r == j) yinv = y;
+        a[j] = lrj;
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+          const double lcj = readlane_f64(lrj, c);
+          a[c] = __builtin_fma(-lrj, lcj, a[c]);  // meaningful for r >= c only; the upper part of a[] is never read
         }
       }
+      if (r < NB) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          if (c <= r) {
+            L.D[r][c] = a[c];
+            if (r < nb) A[(size_t)(kb + r) * lda + kb + c] = a[c];
+          }
+        L.Dinv[r] = yinv;
+        if (rhs != nullptr && r < nb) L.dinv_n[kb + r] = yinv;
+      }
+      if (!ok && lane == 0) *sflag = 1;
+      CHOL_T(9);
+      if (own) load_row(panel_row(tid));
+      CHOL_T_VMWAIT;
+      CHOL_T(10);
+    }
+    CHOL_T(0);
+    __syncthreads();
+    CHOL_T(1);
+    if (*sflag) return false;
+    if (me <= 0) break;
+    for (int p0 = 0; p0 < me; p0 += 384) {  // panel passes (one pass unless n > 400)
+      const int mp = min(384, me - p0);
+      for (int i = tid; i < mp; i += blockDim.x) {  // panel solve: row i of L21 = A21 L11^-T (all 16 columns; padding solves to 0)
+        double* arow = panel_row(p0 + i);
+        if (!(p0 == 0 && i == tid)) load_row(arow);
+        // keep the 136 reads of the diagonal block inside the loop body: hoisted out of it they do not fit the register file
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+          double v = x[c];
+#pragma unroll
+          for (int q = 0; q < c; ++q) v = __builtin_fma(-x[q], L.D[c][q], v);
+          v *= L.Dinv[c];
+          x[c] = v;
+          L.P[i][c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+          if (c < nb) arow[c] = x[c];
+      }
+      for (int i = mp + tid; i < (((rhs != nullptr ? m : mp) + 15) & ~15); i += blockDim.x) {  // rows that only pad the last 16-row tile (the rhs row, index m, multiplies results that are discarded)
+#pragma unroll
+        for (int c = 0; c < NB; ++c) L.P[i][c] = 0.0;
+      }
+      CHOL_T(2);
       __syncthreads();
-      // trailing update restricted to rows of this pass: A[i][k] -= P[i] . P[k] for kb+nb <= k <= i.  Columns k that belong to
-      // an earlier pass need their panel rows too, so with more than one pass we fall back to reading L21 from A.
-      const int T = (mp + 3) / 4;
-      const long ntile = (p0 == 0) ? (long)T * (T + 1) / 2 : 0;
-      for (long q = threadIdx.x; q < ntile; q += blockDim.x) {
-        int tr = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-        while ((long)tr * (tr + 1) / 2 > q) --tr;
-        while ((long)(tr + 1) * (tr + 2) / 2 <= q) ++tr;
-        const int tc = (int)(q - (long)tr * (tr + 1) / 2);
-        double acc[4][4];
+      CHOL_T(3);
+      // trailing update restricted to rows of this pass: A[i][k] -= P[i] . P[k] for kb+nb <= k <= i, 16 x 16 tiles on the matrix
+      // cores (operand element (row l & 15, k = l >> 4) for both factors; result row = (l >> 4) + 4 reg, column = l & 15).
+      // Columns k that belong to an earlier pass need their panel rows too, so with more than one pass we fall back to reading
+      // L21 from A (below).
+      if (p0 == 0) {
+        // The phase is instruction-issue bound (two waves per SIMD), so the tile loop is kept lean: the tile coordinates come
+        // from a table and are made scalar, each access is one instruction (uniform tile base + per-lane offset computed once per
+        // panel), interior tiles carry no predicates, and diagonal tiles are updated in full -- their strictly upper part lands in
+        // the (never referenced) upper triangle of A.  Four tiles per wave are in flight so that the read half of their
+        // read-modify-writes overlaps the matrix-core work.  The right-hand-side row is not part of the tiling (below).
+        const int mt = rhs != nullptr ? m : mp;  // matrix rows of this pass (the right-hand-side row is handled separately)
+        const int T = (mt + 15) / 16;
+        const int ntile = T * (T + 1) / 2;
+        const int lr = lane & 15, lk = lane >> 4;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const int vofs = lk * lda + lr, rstep = 4 * lda;
+        const double* Pl = &L.P[0][0] + (lr * (NB + 1) + lk);
+        double* Abase = A + (size_t)(kb + nb) * lda + kb + nb;
+        constexpr int TU = 4;
+        for (int q0 = wave_u * TU; q0 < ntile; q0 += nwave * TU) {
+          int trv[TU], tcv[TU];
+          double cv[TU][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+          for (int u = 0; u < TU; ++u) {
+            const int t = __builtin_amdgcn_readfirstlane((int)L.tile[min(q0 + u, ntile - 1)]);
+            trv[u] = t >> 8;
+            tcv[u] = t & 255;
+            const double* tb = Abase + (size_t)(trv[u] * 16) * lda + tcv[u] * 16;
+            if (q0 + u < ntile) {
+              if (trv[u] * 16 + 16 <= mt) {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+                for (int rg = 0; rg < 4; ++rg) cv[u][rg] = tb[vofs + rg * rstep];
+              } else {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
-          double pr[4], pc[4];
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            pr[a] = (tr * 4 + a < mp) ? L.P[tr * 4 + a][c] : 0.0;
-            pc[a] = (tc * 4 + a < mp) ? L.P[tc * 4 + a][c] : 0.0;
+                for (int rg = 0; rg < 4; ++rg)
+                  cv[u][rg] = (trv[u] * 16 + lk + 4 * rg < mt && tcv[u] * 16 + lr < mt) ? tb[vofs + rg * rstep] : 0.0;
+              }
+            }
           }
 #pragma unroll
-          for (int a = 0; a < 4; ++a)
+          for (int u = 0; u < TU; ++u) {
+            if (q0 + u >= ntile) break;
+            const double* pa = Pl + trv[u] * 16 * (NB + 1);
+            const double* pb = Pl + tcv[u] * 16 * (NB + 1);
+            f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += pr[a] * pc[b];
+            for (int k0 = 0; k0 < NB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+            double* tb = Abase + (size_t)(trv[u] * 16) * lda + tcv[u] * 16;
+            if (trv[u] * 16 + 16 <= mt) {
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) tb[vofs + rg * rstep] = cv[u][rg] - acc[rg];
+            } else {
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg)
+                if (trv[u] * 16 + lk + 4 * rg < mt && tcv[u] * 16 + lr < mt) tb[vofs + rg * rstep] = cv[u][rg] - acc[rg];
+            }
+          }
         }
+        if (rhs != nullptr) {  // the right-hand-side row: rhs[k] -= P[m] . P[k]
+          for (int k = tid; k < m; k += blockDim.x) {
+            double acc = 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int i = tr * 4 + a, k = tc * 4 + b;
-            if (i < mp && k <= i) A[(size_t)(kb + nb + i) * lda + kb + nb + k] -= acc[a][b];
+            for (int c = 0; c < NB; ++c) acc = __builtin_fma(L.P[m][c], L.P[k][c], acc);
+            rhs[kb + nb + k] -= acc;
           }
+        }
       }
-      if (p0 != 0 || m > 384) {  // generic (slow) path for matrices larger than one panel pass: element-wise from global memory
-        for (long q = threadIdx.x; q < (long)mp * m; q += blockDim.x) {
+      if (p0 != 0 || me > 384) {  // generic (slow) path for matrices larger than one panel pass: element-wise from global memory
+        for (long q = tid; q < (long)mp * m; q += blockDim.x) {
           const int i = p0 + (int)(q / m), k = (int)(q % m);
           if (k > i || (p0 == 0 && k < mp)) continue;
           double sacc = 0.0;
@@ -565,7 +878,9 @@ __device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, in
           A[(size_t)(kb + nb + i) * lda + kb + nb + k] -= sacc;
         }
       }
+      CHOL_T(4);
       __syncthreads();
+      CHOL_T(5);
     }
   }
   __syncthreads();
@@ -620,6 +935,60 @@ __device__ __forceinline__ void wave_backward(const double* __restrict__ L, int 
   }
 }
 
+// Backward substitution L^T x = y for one right-hand side in LDS by the whole workgroup (n <= blockDim.x, n < 384), after a
+// block_cholesky that carried a right-hand side (C.dinv_n holds the inverse diagonal).  Thread i keeps x[i] in a register and
+// column i of the current 16-row block of L in registers (coalesced loads; the next block is requested before the current one is
+// used).  Per block the 16 owners publish their entries and the 16 x 16 diagonal block in LDS (double buffered: ONE barrier per
+// block), every wave then solves the small transposed system redundantly in registers (v_readlane broadcasts) and each thread
+// to the left removes the 16 new unknowns from its own entry.
+__device__ __forceinline__ void block_backward(const double* __restrict__ Lm, int n, int lda, double* __restrict__ x, CholLds& C) {
+  constexpr int NB = kCholNB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  double cur[NB], nxt[NB];
+  const int kb_last = ((n - 1) / NB) * NB;
+  auto fetch = [&](int kb, double* dst) {
+    const int nb = min(NB, n - kb);
+#pragma unroll
+    for (int c = 0; c < NB; ++c) dst[c] = (c < nb && tid <= kb + c) ? Lm[(size_t)(kb + c) * lda + tid] : 0.0;
+  };
+  fetch(kb_last, cur);
+  double xv = tid < n ? x[tid] : 0.0;
+  // staging: buffer b = rows [b * 17, b * 17 + 16) of the panel array hold the diagonal block, row b * 17 + 16 the 16 entries of x
+  int buf = 0;
+  const int r = lane & 15;
+  for (int kb = kb_last; kb >= 0; kb -= NB) {
+    const int nb = min(NB, n - kb);
+    if (kb >= NB) fetch(kb - NB, nxt);
+    double (*Db)[NB + 1] = &C.P[buf * (NB + 1)];
+    if (tid >= kb && tid < kb + nb) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) Db[c][tid - kb] = cur[c];  // Db[c][q] = L[kb + c][kb + q], q <= c
+      Db[NB][tid - kb] = xv;
+    }
+    __syncthreads();
+    double v = r < nb ? Db[NB][r] : 0.0;
+    const double dinv = r < nb ? C.dinv_n[kb + r] : 1.0;
+    double dcol[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dcol[j] = (j > r && j < nb) ? Db[j][r] : 0.0;
+#pragma unroll
+    for (int j = NB - 1; j >= 0; --j) {
+      const double xj = readlane_f64(v, j) * readlane_f64(dinv, j);
+      if (r == j) v = xj;
+      v = __builtin_fma(-dcol[j], xj, v);  // dcol[j] is zero for j <= r
+    }
+    if (tid < nb) x[kb + tid] = v;
+    if (tid < kb) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c) xv = __builtin_fma(-cur[c], readlane_f64(v, c), xv);
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) cur[c] = nxt[c];
+    buf ^= 1;
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ double block_sum(double v, double* sred) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -645,7 +1014,7 @@ __device__ __forceinline__ double block_max(double v, double* sred) {
 
 // grid: (6 channels, windows), block 256.  preint.h:832-866 for one channel.
 __global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.y];
+  const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0) return;
   const int c = blockIdx.x, S = w.S;
   const double l2 = w.hyper[c * 4 + 0], sf2 = w.hyper[c * 4 + 1], sz2 = w.hyper[c * 4 + 2];
@@ -729,7 +1098,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ w
 // grid: (12 tables, windows, row tiles of 8), block 256.  Tables 0-2 K_s K^-1 (gyro stamps), 3-5 K_s_int K^-1 (gyro stamps),
 // 6-8 K_s_int K^-1 (velocity stamps, rotation channels), 9-11 K_s K^-1 (velocity stamps, velocity channels).
 __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.y];
+  const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0) return;
   const int tab = blockIdx.x, S = w.S;
   const int c = tab % 3, kind = tab / 3;
@@ -818,7 +1187,7 @@ __device__ void gpnorm_rows(const UgpmWin& w, int ch, const double* __restrict__
 // grid: (windows, splits), block 256: the workgroups of one window share its samples.  mode: 0 residual at x_new -> res_new; 1 residual + Jacobian at x -> res, Jrot; 2 as 1 and also
 // (re)writes the constant GpNorm blocks and zeroes the rest (first evaluation).
 __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict__ wins, int mode) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || w.lmi[1]) return;
   if (mode == 1 && !w.lmi[3]) return;  // Jacobian only needed after an accepted step
   const int S = w.S, G = w.G, n = 3 * S;
@@ -875,7 +1244,7 @@ __device__ __forceinline__ V3 vel_rot_vec(const UgpmWin& w, int i) {
 
 // Problem #2 (preint.h:954-967): rotation states constant; x = [s_vel0 | s_vel1 | s_vel2]; rows = VelCost (3V) then 3 GpNorm (3S).
 __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict__ wins, int mode) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || w.lmi[1]) return;
   if (mode == 1 && !w.lmi[3]) return;
   const int S = w.S, V = w.V, n = 3 * S;
@@ -916,7 +1285,7 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
 // Stacked Jacobian of the correlation step at the LPM-initialised state (preint.h:887-937): rows 3G (RotCost) + 3V (VelCost),
 // columns 6S = [rot channels | velocity channels].  grid: (windows), block 256.
 __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || !w.correlate) return;
   const int S = w.S, G = w.G, V = w.V, n = 6 * S;
   double* J = w.Jc;
@@ -971,10 +1340,8 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
 // output tile (4 waves x 32 x 32 = 2 x 2 MFMA tiles each); only tiles with tj >= ti are computed and mirrored.
 // f64 C/D layout (16x16x4): col = lane & 15, row = (lane >> 4) + 4 * reg.   g = A^T r is formed by the tile row ti == 0.
 // grid: (tiles, tiles, windows).  which: 0 rot problem, 1 vel problem, 2 correlation.
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
 __global__ __launch_bounds__(256) void ata_kernel(const UgpmWin* __restrict__ wins, int which) {
-  const UgpmWin& w = wins[blockIdx.z];
+  const UgpmWin w = load_win(wins, blockIdx.z);
   if (*w.status != 0) return;
   int m, n;
   const double* A;
@@ -1049,7 +1416,7 @@ __global__ __launch_bounds__(256) void ata_kernel(const UgpmWin* __restrict__ wi
 
 // start a problem: load x, reset the control block.  grid: (windows), block 256.
 __global__ __launch_bounds__(256) void lm_begin_kernel(const UgpmWin* __restrict__ wins, int problem) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0) return;
   const int n = 3 * w.S;
   const double* src = problem == 0 ? w.s_dr : w.s_vel;
@@ -1067,7 +1434,7 @@ __global__ __launch_bounds__(256) void lm_begin_kernel(const UgpmWin* __restrict
 // One trust-region step: (on fresh J^T J) cost / gradient test / Jacobi scaling, then solve (D J^T J D + diag / radius) y = D g,
 // step = -y, delta = D step, model cost change, candidate x_new.  grid: (windows), block 256.
 __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || w.lmi[1]) return;
   const int n = 3 * w.S;
   const int problem = w.lmi[7];
@@ -1124,23 +1491,37 @@ __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict_
     for (int j = threadIdx.x; j < n; j += blockDim.x) diag[j] = fmin(fmax(w.JtJ[(size_t)j * n + j] * scale[j] * scale[j], 1e-6), 1e32);
   __syncthreads();
   double* L = w.lhs;
-  for (size_t q = threadIdx.x; q < (size_t)n * n; q += blockDim.x) {
-    const int i = (int)(q / n), j = (int)(q % n);
-    if (j <= i) L[q] = w.JtJ[q] * scale[i] * scale[j] + (i == j ? diag[i] / radius : 0.0);
+  __shared__ double xs[kCholMaxN / 2];
+  const bool fused = n < 384 && n <= (int)blockDim.x && n <= kCholMaxN / 2;  // rhs rides through the factorisation, blocked back-substitution
+  for (int i = threadIdx.x >> 6; i < n; i += (int)(blockDim.x >> 6)) {  // lower triangle of D J^T J D + diag / radius, one row per wave
+    const double si = scale[i];
+    for (int j = threadIdx.x & 63; j <= i; j += 64)
+      L[(size_t)i * n + j] = w.JtJ[(size_t)i * n + j] * si * scale[j] + (i == j ? diag[i] / radius : 0.0);
   }
-  for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = g[j] * scale[j];
+  double* rhs = w.lmv + 7 * (size_t)n;  // right-hand side row carried through the factorisation (global, like the matrix)
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    step[j] = g[j] * scale[j];
+    if (fused) rhs[j] = g[j] * scale[j];
+  }
   __syncthreads();
-  bool valid = block_cholesky(L, n, n, chol, &sflag);
+  bool valid = block_cholesky(L, n, n, chol, &sflag, fused ? rhs : nullptr);
   if (valid) {
-    double* xs = &chol.P[0][0];  // the panel buffer is free again: solve in LDS
-    for (int j = threadIdx.x; j < n; j += blockDim.x) xs[j] = step[j];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      wave_forward<1>(L, n, n, xs, 1, 0);
-      wave_backward(L, n, n, xs);
+    if (fused) {
+      for (int j = threadIdx.x; j < n; j += blockDim.x) xs[j] = rhs[j];
+      __syncthreads();
+      block_backward(L, n, n, xs, chol);
+      for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = xs[j];
+    } else {
+      double* xp = &chol.P[0][0];  // the panel buffer is free again: solve in LDS
+      for (int j = threadIdx.x; j < n; j += blockDim.x) xp[j] = step[j];
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        wave_forward<1>(L, n, n, xp, 1, 0);
+        wave_backward(L, n, n, xp);
+      }
+      __syncthreads();
+      for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = xp[j];
     }
-    __syncthreads();
-    for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = xs[j];
     __syncthreads();
     double bad = 0.0;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
@@ -1154,9 +1535,9 @@ __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict_
   double mcc = 0.0, sn = 0.0;
   if (valid) {  // model cost change -(J d)^T (r + J d / 2) = -(d.g + d^T (J^T J) d / 2)
     double acc = 0.0;
-    for (size_t q = threadIdx.x; q < (size_t)n * n; q += blockDim.x) {  // 0.5 d^T (J^T J) d, coalesced over the matrix
-      const int i = (int)(q / n), j = (int)(q % n);
-      acc += 0.5 * delta[i] * w.JtJ[q] * delta[j];
+    for (int i = threadIdx.x >> 6; i < n; i += (int)(blockDim.x >> 6)) {  // 0.5 d^T (J^T J) d, one matrix row per wave (coalesced)
+      const double hi = 0.5 * delta[i];
+      for (int j = threadIdx.x & 63; j < n; j += 64) acc += hi * w.JtJ[(size_t)i * n + j] * delta[j];
     }
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       acc += delta[i] * g[i];
@@ -1176,7 +1557,7 @@ __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict_
 
 // After the candidate residuals: cost, tolerances, acceptance, radius update.  grid: (windows), block 256.
 __global__ __launch_bounds__(256) void lm_decide_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || w.lmi[1]) return;
   const int n = 3 * w.S;
   const int problem = w.lmi[7];
@@ -1228,7 +1609,7 @@ __global__ __launch_bounds__(256) void lm_decide_kernel(const UgpmWin* __restric
 
 // write the solution back into the state.  grid: (windows), block 256.
 __global__ __launch_bounds__(256) void lm_end_kernel(const UgpmWin* __restrict__ wins, int problem, double* __restrict__ diag_out /* [windows][4] */) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0) return;
   const int n = 3 * w.S;
   double* dst = problem == 0 ? w.s_dr : w.s_vel;
@@ -1243,7 +1624,7 @@ __global__ __launch_bounds__(256) void lm_end_kernel(const UgpmWin* __restrict__
 
 // A = J^T J + 1e-5 I = L L^T, L^-1, dsc = state_std / sqrt(diag(A^-1)) (preint.h:1478-1492).  grid: (windows), block 1024.
 __global__ __launch_bounds__(512) void corr_factor_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || !w.correlate) return;
   const int n = 6 * w.S;
   __shared__ int sflag;
@@ -1259,7 +1640,7 @@ __global__ __launch_bounds__(512) void corr_factor_kernel(const UgpmWin* __restr
 // diag(A^-1) = column norms of L^-1, 16 columns per workgroup (4 per wave), unit right-hand sides in LDS; then
 // dsc = state_std / sqrt(diag(A^-1)) (preint.h:1487-1489).  grid: (ceil(6S / 16), windows), block 256.
 __global__ __launch_bounds__(256) void corr_diag_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.y];
+  const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0 || !w.correlate) return;
   const int n = 6 * w.S;
   const int j0 = blockIdx.x * 16;
@@ -1292,7 +1673,7 @@ __global__ __launch_bounds__(256) void corr_diag_kernel(const UgpmWin* __restric
 
 // preint.h:978-1060 and finishStateDiff (preint.h:1401-1441).  grid: (windows), block 256.
 __global__ __launch_bounds__(256) void finish_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.x];
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0) return;
   const int S = w.S;
   for (int q = threadIdx.x; q < 6 * S; q += blockDim.x) {  // alpha = K^-1 s
@@ -1360,7 +1741,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const UgpmWin* __restrict__
 // Se3Integrator::get(t) (preint.h:1069-1153) + cov inflation of VelPreintegration::get (preint.h:1744-1757).
 // grid: (max n_infer, windows), block 256.
 __global__ __launch_bounds__(256) void infer_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin& w = wins[blockIdx.y];
+  const UgpmWin w = load_win(wins, blockIdx.y);
   const int qi = blockIdx.x;
   if (qi >= w.n_infer) return;
   double* out = w.out + (size_t)qi * 83;
