@@ -33,7 +33,7 @@ struct Ctx {  // per-thread, per-device cached buffers
   size_t ws_cap = 0;
   UgpmWin* d_wins = nullptr;
   int wins_cap = 0;
-  int* d_ints = nullptr;  // per window: lmi[16] + status[1] -> 17 ints
+  int* d_ints = nullptr;  // per window: kWinInts ints (lmi[16], status, ata_cnt[])
   double* d_diag = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   std::vector<int> ev_stage;
@@ -99,6 +99,10 @@ size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* b
   u.Jrot = take(mrot * n); u.Jvel = take(mvel * n); u.res = take(std::max(mrot, mvel)); u.res_new = take(std::max(mrot, mvel));
   u.JtJ = take(n * n); u.lhs = take(n * n); u.lmv = take(8 * n); u.sample_tmp = take(std::max(G, V) * 24);
   if (w.correlate) { u.Jc = take(mc * nc); u.Ac = take(nc * nc); }
+  {
+    const size_t nmax = w.correlate ? nc : n, tmax = (nmax + 15) / 16, tiles = tmax * (tmax + 1) / 2;
+    u.ata_part = take(kAtaKSplit * (tiles * 256 + nmax));
+  }
   u.dsc = take(nc);
   u.alpha = take(6 * S); u.state_r = take(3 * S); u.d_state_bw = take(3 * S * 3); u.d_d_r_dt = take(3 * S); u.d_vel_bv = take(3 * S * 3); u.d_vel_bw = take(3 * S * 3);
   u.d_vel_dt = take(3 * S); u.out = outp; u.lmc = take(16);
@@ -179,6 +183,10 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi) == hipSuccess) made = true;
     }
     if (!made) UHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    // ata_kernel stages J through up to ~128 KB of dynamic LDS (the default limit is 64 KB)
+    UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
   }
   for (int i = 0; i < 5; ++i) { g_stage_s[i] = 0; g_stage_n[i] = 0; }
   const bool trace = std::getenv("GORIO_UGPM_TRACE") != nullptr;
@@ -243,7 +251,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag);
     c.d_wins = nullptr; c.d_ints = nullptr; c.d_diag = nullptr;
     UHIP(hipMalloc(&c.d_wins, sizeof(UgpmWin) * n_windows));
-    UHIP(hipMalloc(&c.d_ints, sizeof(int) * 17 * n_windows));
+    UHIP(hipMalloc(&c.d_ints, sizeof(int) * kWinInts * n_windows));
     UHIP(hipMalloc(&c.d_diag, sizeof(double) * 4 * n_windows));
     c.wins_cap = n_windows;
   }
@@ -251,7 +259,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   // ---- carve the workspace, stage the inputs
   std::vector<UgpmWin> dw(n_windows);
   std::vector<double> stage_in;
-  std::vector<int> ints(17 * (size_t)n_windows, 0);
+  std::vector<int> ints(kWinInts * (size_t)n_windows, 0);
   double* in_region = c.ws;
   double* out_region = c.ws + total_in;
   double* base = out_region + (total_out + 31) / 32 * 32;
@@ -263,9 +271,10 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     HostWin& h = hw[i];
     UgpmWin& u = dw[i];
     std::memset(&u, 0, sizeof(u));
-    u.lmi = c.d_ints + 17 * (size_t)i;
-    u.status = c.d_ints + 17 * (size_t)i + 16;
-    ints[17 * (size_t)i + 16] = h.status;
+    u.lmi = c.d_ints + kWinInts * (size_t)i;
+    u.status = c.d_ints + kWinInts * (size_t)i + 16;
+    u.ata_cnt = c.d_ints + kWinInts * (size_t)i + 20;
+    ints[kWinInts * (size_t)i + 16] = h.status;
     u.n_infer = std::max(0, w.n_infer);
     out_offs[i] = out_off;
     u.out = out_region + out_off;
@@ -306,7 +315,19 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   const int max_G = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.G); return m; }();
   const int max_V = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.V); return m; }();
   if (max_S > 0) {
-    const int tiles_n = (3 * max_S + 63) / 64, tiles_c = (6 * max_S + 63) / 64;
+    // J^T J launches: one workgroup per (row slice, tile group, window), see ata_kernel
+    auto launch_ata = [&](int which) {
+      const int n = (which == 2 ? 6 : 3) * max_S, T = (n + 15) / 16, ntile = T * (T + 1) / 2;
+      const int ng = (ntile + kAtaTilesPerGroup - 1) / kAtaTilesPerGroup;
+      const int npad = ((n + 15) / 32) * 32 + 16;
+      const int units = nw * ng, grid = ((units + 7) / 8) * kAtaKSplit * 8;
+      // at least 84 KB of LDS per workgroup: two of them must not share a CU (they would halve each other's matrix-core rate
+      // while other CUs idle)
+      auto lds = [&](int kc) { return std::max(sizeof(double) * 2 * kc * (npad + 1), (size_t)84 * 1024); };
+      if (npad <= 256) ug::ata_kernel<4, 16><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
+      else if (npad <= 512) ug::ata_kernel<8, 16><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
+      else ug::ata_kernel<16, 8><<<grid, 512, lds(8), c.stream>>>(c.d_wins, which, nw, ng);
+    };
     {
       Stage st(c, 0);
       ug::lpm_init_kernel<<<nw, 320, 0, c.stream>>>(c.d_wins);
@@ -319,17 +340,17 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     {
       Stage st(c, 2);  // state correlation at the LPM-initialised state (a side thread in the reference, preint.h:939)
       ug::corr_jac_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
-      ug::ata_kernel<<<dim3(tiles_c, tiles_c, nw), 256, 0, c.stream>>>(c.d_wins, 2);
+      launch_ata(2);
       ug::corr_factor_kernel<<<nw, 512, 0, c.stream>>>(c.d_wins);
       ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, nw), 256, sizeof(double) * 17 * 6 * max_S, c.stream>>>(c.d_wins);
     }
-    std::vector<int> flags(17 * (size_t)nw);
+    std::vector<int> flags(kWinInts * (size_t)nw);
     for (int problem = 0; problem < 2; ++problem) {  // ceres::Solve #1 (rotation) and #2 (velocity), preint.h:943-967
       Stage st(c, 3);
       ug::lm_begin_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, problem);
       if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 2);
       else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 2);
-      ug::ata_kernel<<<dim3(tiles_n, tiles_n, nw), 256, 0, c.stream>>>(c.d_wins, problem);
+      launch_ata(problem);
       for (int it = 0; it <= 51; ++it) {
         ug::lm_step_kernel<<<nw, 512, 0, c.stream>>>(c.d_wins);
         if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
@@ -337,12 +358,12 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
         ug::lm_decide_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
         if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
         else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
-        ug::ata_kernel<<<dim3(tiles_n, tiles_n, nw), 256, 0, c.stream>>>(c.d_wins, problem);
+        launch_ata(problem);
         if ((it & 1) == 1) {  // poll the done flags every other iteration
           UHIP(hipMemcpyAsync(flags.data(), c.d_ints, sizeof(int) * flags.size(), hipMemcpyDeviceToHost, c.stream));
           UHIP(hipStreamSynchronize(c.stream));
           bool all = true;
-          for (int i = 0; i < nw; ++i) all = all && (flags[17 * (size_t)i + 1] || flags[17 * (size_t)i + 16] != 0);
+          for (int i = 0; i < nw; ++i) all = all && (flags[kWinInts * (size_t)i + 1] || flags[kWinInts * (size_t)i + 16] != 0);
           if (all) break;
         }
       }
@@ -357,7 +378,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   }
   tt3 = tnow();
   // ---- results
-  std::vector<int> fin(17 * (size_t)nw);
+  std::vector<int> fin(kWinInts * (size_t)nw);
   std::vector<double> dg(4 * (size_t)nw);
   UHIP(hipMemcpyAsync(fin.data(), c.d_ints, sizeof(int) * fin.size(), hipMemcpyDeviceToHost, c.stream));
   UHIP(hipMemcpyAsync(dg.data(), c.d_diag, sizeof(double) * dg.size(), hipMemcpyDeviceToHost, c.stream));
@@ -379,7 +400,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       double* o = reinterpret_cast<double*>(out) + out_offs[i];
       for (size_t k = 0; k < (size_t)std::max(0, windows[i].n_infer) * 83; ++k) o[k] = std::numeric_limits<double>::quiet_NaN();
     }
-    int st = hw[i].status != 0 ? hw[i].status : fin[17 * (size_t)i + 16];
+    int st = hw[i].status != 0 ? hw[i].status : fin[kWinInts * (size_t)i + 16];
     if (st != 0 && hw[i].status == 0 && !first_error) {
       first_error = st;
       first_error_msg = "window " + std::to_string(i) + (st == GORIO_UGPM_ERR_NUMERIC ? ": Cholesky factorisation met a non-positive pivot" : ": LPM Partial: the start_time is not in the data domain");

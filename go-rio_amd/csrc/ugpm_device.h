@@ -8,6 +8,11 @@
 
 namespace gorio {
 
+constexpr int kAtaKSplit = 4;       // workgroups sharing the rows of J for one group of output tiles
+constexpr int kAtaTilesPerGroup = 96;  // 16 x 16 output tiles per workgroup (8 waves x 12 accumulators)
+constexpr int kAtaMaxGroups = 28;
+constexpr int kWinInts = 48;        // ints per window: lmi[16], status at 16, ata_cnt at 20
+
 struct UgpmWin {
   // ---- inputs
   const double* gyr_t;  // [G]
@@ -76,6 +81,10 @@ struct UgpmWin {
   double* lmc;  // [16]: 0 cost, 1 cost_new, 2 radius, 3 decrease_factor, 4 x_norm, 5 model_cost_change, 6 step_norm, 7 cost0
   int* lmi;     // [16]: 0 iter, 1 done, 2 reuse_diag, 3 need_J, 4 step_valid, 5 termination, 6 successful, 7 problem (0 rot, 1 vel)
   int* status;  // [1] per-window gorio_ugpm_status
+  // J^T J split over workgroups (ata_kernel): partial tiles [kAtaKSplit][tiles][256] followed by partial gradients [kAtaKSplit][n],
+  // and one arrival counter per tile group (zero between launches)
+  double* ata_part;
+  int* ata_cnt;  // [kAtaMaxGroups]
 };
 
 }  // namespace gorio

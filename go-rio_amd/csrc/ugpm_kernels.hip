@@ -1334,14 +1334,29 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
 
 // =============================================================================================== J^T J
 
-// C = A^T A for A (m x n, row-major) on the fp64 matrix cores: v_mfma_f64_16x16x4_f64 takes A^T as its 16 x 4 operand and A as
-// its 4 x 16 operand, and BOTH are plain row segments of A (lane l reads A[k0 + (l >> 4)][c0 + (l & 15)], 128 B contiguous per
-// k-row), so the operands stream straight from L2 into the matrix pipe with no LDS transpose.  One workgroup owns a 64 x 64
-// output tile (4 waves x 32 x 32 = 2 x 2 MFMA tiles each); only tiles with tj >= ti are computed and mirrored.
-// f64 C/D layout (16x16x4): col = lane & 15, row = (lane >> 4) + 4 * reg.   g = A^T r is formed by the tile row ti == 0.
-// grid: (tiles, tiles, windows).  which: 0 rot problem, 1 vel problem, 2 correlation.
-__global__ __launch_bounds__(256) void ata_kernel(const UgpmWin* __restrict__ wins, int which) {
-  const UgpmWin w = load_win(wins, blockIdx.z);
+// C = A^T A (and g = A^T r) for A (m x n, row-major) on the fp64 matrix cores.
+// v_mfma_f64_16x16x4_f64 takes A^T as its 16 x 4 operand and A as its 4 x 16 operand; BOTH are row segments of A (lane l supplies
+// A[k0 + (l >> 4)][c0 + (l & 15)]), so no transpose is ever formed.  Result layout: col = lane & 15, row = (lane >> 4) + 4 reg.
+// Work split: the lower-triangular 16 x 16 tiling of C is cut into groups of <= 96 tiles (12 accumulators per wave, 8 waves) and
+// the rows of A into kAtaKSplit slices; one workgroup owns (slice, group).  It streams its rows through LDS in chunks of 16 (8
+// for n > 496) -- every element of A is read from L2 once per group instead of once per output tile -- and writes its partial
+// tiles in accumulator order (fully coalesced).  The LAST of the kAtaKSplit workgroups of a group to finish (arrival counter) adds
+// the partials in slice order, so the result does not depend on the order of arrival, and writes C symmetrically.
+// grid: 1-D, ceil(units * kAtaKSplit / 8) * 8 workgroups with unit = (window, group): the kAtaKSplit workgroups of a unit are 8
+// apart in launch order, i.e. on the same XCD (workgroups are dealt to XCDs round-robin), so their partials meet in one L2.
+// which: 0 rot problem, 1 vel problem, 2 correlation.  Dynamic LDS: 2 * KC * (npad + 1) doubles.  n <= 512 when g is formed.
+__device__ __forceinline__ int ata_npad(int n) { return ((n + 15) / 32) * 32 + 16; }  // >= round_up(n, 16); rows 32 banks apart
+
+// CMAX = 64-column groups of a staged row (npad <= 64 CMAX), KC = rows per staged chunk.
+template <int CMAX, int KC>
+__global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wins, int which, int n_windows, int groups_max) {
+  const int L = blockIdx.x;
+  const int xcd = L & 7, pslot = L >> 3;
+  const int ks = pslot % kAtaKSplit;
+  const int unit = (pslot / kAtaKSplit) * 8 + xcd;
+  const int win = unit / groups_max, grp = unit % groups_max;
+  if (win >= n_windows) return;
+  const UgpmWin w = load_win(wins, win);
   if (*w.status != 0) return;
   int m, n;
   const double* A;
@@ -1358,55 +1373,147 @@ __global__ __launch_bounds__(256) void ata_kernel(const UgpmWin* __restrict__ wi
     A = which == 0 ? w.Jrot : w.Jvel;
     C = w.JtJ; r = w.res; g = w.lmv;
   }
-  const int ti = blockIdx.x, tj = blockIdx.y;
-  if (tj < ti || ti * 64 >= n || tj * 64 >= n) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i0 = ti * 64 + (wave >> 1) * 32, j0 = tj * 64 + (wave & 1) * 32;
+  const int T = (n + 15) / 16, ntile = T * (T + 1) / 2;
+  const int ng = (ntile + kAtaTilesPerGroup - 1) / kAtaTilesPerGroup;
+  if (grp >= ng) return;
+  const int q_lo = (int)((long)grp * ntile / ng), q_hi = (int)((long)(grp + 1) * ntile / ng);
+  const int npad = ata_npad(n);
+  const int nck = (m + KC - 1) / KC;
+  const int c_lo = ks * nck / kAtaKSplit, c_hi = (ks + 1) * nck / kAtaKSplit;
+  extern __shared__ double ata_lds[];  // [2][KC][npad] staged rows of A, then [2][KC] staged entries of r
+  double* rl = ata_lds + (size_t)2 * KC * npad;
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
-  f64x4 acc[2][2];
+  constexpr int NT = 12;
+  // this wave's tiles: q = q_lo + wave + 8 t.  Slots past the end of the group repeat the group's last tile (computed, not stored):
+  // the loop below then has no branches and the compiler can keep all operand reads of a k-step in flight ahead of the MFMAs.
+  int trofs[NT], tcofs[NT], qv[NT];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) acc[p][q] = f64x4{0.0, 0.0, 0.0, 0.0};
-  const bool ci0 = i0 + lr < n, ci1 = i0 + 16 + lr < n, cj0 = j0 + lr < n, cj1 = j0 + 16 + lr < n;
-  const double* pa0 = A + i0 + lr;
-  const double* pb0 = A + j0 + lr;
-#pragma unroll 4
-  for (int k0 = 0; k0 < m; k0 += 4) {
-    const int k = k0 + lk;
-    const bool kv = k < m;
-    const size_t ro = (size_t)k * n;
-    const double a0 = (kv && ci0) ? pa0[ro] : 0.0;
-    const double a1 = (kv && ci1) ? pa0[ro + 16] : 0.0;
-    const double b0 = (kv && cj0) ? pb0[ro] : 0.0;
-    const double b1 = (kv && cj1) ? pb0[ro + 16] : 0.0;
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  for (int t = 0; t < NT; ++t) {
+    const int q = min(q_lo + wave + 8 * t, q_hi - 1);
+    int tr = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+    while (tr * (tr + 1) / 2 > q) --tr;
+    while ((tr + 1) * (tr + 2) / 2 <= q) ++tr;
+    qv[t] = __builtin_amdgcn_readfirstlane(q);
+    trofs[t] = __builtin_amdgcn_readfirstlane(tr) * 16;
+    tcofs[t] = __builtin_amdgcn_readfirstlane(q - tr * (tr + 1) / 2) * 16;
   }
+  const int nt = max(0, min(NT, (q_hi - q_lo - wave + 7) / 8));
+  f64x4 acc[NT];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double gacc = 0.0;
+  // chunk loader: wave v brings rows v, v + 8 (KC = 16) of the chunk, 64 columns per instruction
+  constexpr int RMAX = KC / 8;
+  double pre[RMAX][CMAX];
+  double rpre = 0.0;
+  auto fetch = [&](int ck) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int rr = 0; rr < RMAX; ++rr) {
+      const int k = ck * KC + wave + 8 * rr;
+#pragma unroll
+      for (int cc = 0; cc < CMAX; ++cc) {
+        const int col = lane + 64 * cc;
+        pre[rr][cc] = (k < m && col < n) ? A[(size_t)k * n + col] : 0.0;
+      }
+    }
+    if (r != nullptr && tid < KC) rpre = (ck * KC + tid < m) ? r[ck * KC + tid] : 0.0;
+  };
+  auto stash = [&](int buf) {
+    double* dst = ata_lds + (size_t)buf * KC * npad;
+#pragma unroll
+    for (int rr = 0; rr < RMAX; ++rr) {
+      const int row = wave + 8 * rr;
+#pragma unroll
+      for (int cc = 0; cc < CMAX; ++cc) {
+        const int col = lane + 64 * cc;
+        if (col < npad) dst[row * npad + col] = pre[rr][cc];
+      }
+    }
+    if (tid < KC) rl[buf * KC + tid] = rpre;
+  };
+  CHOL_T_INIT;
+  if (c_lo < c_hi) {
+    fetch(c_lo);
+    stash(0);
+  }
+  __syncthreads();
+  CHOL_T(0);
+  for (int ck = c_lo; ck < c_hi; ++ck) {
+    const int buf = (ck - c_lo) & 1;
+    if (ck + 1 < c_hi) fetch(ck + 1);
+    const double* src = ata_lds + (size_t)buf * KC * npad;
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 4) {
+      const double* rowp = src + (kk + lk) * npad + lr;
+      double av[NT], bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        av[t] = rowp[trofs[t]];
+        bv[t] = rowp[tcofs[t]];
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc[t], 0, 0, 0);
+    }
+    CHOL_T(1);
+    if (g != nullptr && grp == 0 && tid < n) {
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) gacc += src[kk * npad + tid] * rl[buf * KC + kk];
+    }
+    CHOL_T(2);
+    if (ck + 1 < c_hi) stash(buf ^ 1);
+    CHOL_T(3);
+    __syncthreads();
+    CHOL_T(4);
+  }
+  // partial results, accumulator order: [(ks * ntile + q) * 256 + reg * 64 + lane]
+  double* part = w.ata_part;
+  double* gpart = part + (size_t)kAtaKSplit * ntile * 256;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt) {
+      double* dst = part + ((size_t)ks * ntile + qv[t]) * 256 + lane;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) dst[rg * 64] = acc[t][rg];
+    }
+  }
+  if (g != nullptr && grp == 0 && tid < n) gpart[(size_t)ks * n + tid] = gacc;
+  CHOL_T(5);
+  __threadfence();
+  __syncthreads();
+  CHOL_T(6);
+  if (tid == 0) {
+    const int prev = atomicAdd(w.ata_cnt + grp, 1);
+    s_last = prev == kAtaKSplit - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t < nt) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int i = i0 + p * 16 + lk + 4 * rg, j = j0 + q * 16 + lr;
+        double v = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < kAtaKSplit; ++s2) v += part[((size_t)s2 * ntile + qv[t]) * 256 + rg * 64 + lane];
+        const int i = trofs[t] + lk + 4 * rg, j = tcofs[t] + lr;
         if (i < n && j < n) {
-          C[(size_t)i * n + j] = acc[p][q][rg];
-          C[(size_t)j * n + i] = acc[p][q][rg];
+          C[(size_t)i * n + j] = v;
+          C[(size_t)j * n + i] = v;
         }
       }
-  if (g != nullptr && ti == 0) {  // g[j] = sum_k A[k][j] r[k] for the 64 columns of tile column tj: 4 k-slices, LDS tree
-    __shared__ double sg[4][64];
-    const int j = tj * 64 + lane;
-    double s = 0.0;
-    if (j < n)
-      for (int k = wave; k < m; k += 4) s += A[(size_t)k * n + j] * r[k];
-    sg[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0 && j < n) g[j] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+    }
   }
+  if (g != nullptr && grp == 0 && tid < n) {
+    double v = 0.0;
+#pragma unroll
+    for (int s2 = 0; s2 < kAtaKSplit; ++s2) v += gpart[(size_t)s2 * n + tid];
+    g[tid] = v;
+  }
+  if (tid == 0) w.ata_cnt[grp] = 0;
+  CHOL_T(7);
 }
 
 // =============================================================================================== Levenberg-Marquardt (Ceres 2.1 defaults + preint.h:943-948)
