@@ -20,8 +20,9 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 def build(force: bool = False) -> str:
     """Compile every HIP source for gfx950 into go-rio_amd/lib/libgorio_amd.so (hipcc cross-compiles without a GPU)."""
     import subprocess
+    import sys
 
-    subprocess.check_call(["make", "-C", CSRC_DIR] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-C", CSRC_DIR] + (["-B"] if force else []), stdout=sys.stderr)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"build did not produce {LIB_PATH}")
     return LIB_PATH
@@ -29,4 +30,4 @@ def build(force: bool = False) -> str:
 
 from . import synth  # noqa: E402  (pure-numpy synthetic inputs, no GPU)
 from .apd import ApdGicp, ApdParams, GorioError, align_batch, load_library  # noqa: E402
-from .ugpm import PreintOption, PreintPrior, VelPreintegration, ugpm_preint_batch, ugpm_stage_times  # noqa: E402
+from .ugpm import PreintOption, PreintPrior, UgpmBatch, VelPreintegration, ugpm_preint_batch, ugpm_stage_times  # noqa: E402

@@ -303,6 +303,21 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   // candidates farther than the correspondence gate can never be accepted (APD:183): start from the gate as the bound
   unsigned long long best = ((unsigned long long)__float_as_uint(bound_f) << 32) | 0xffffffffull;
   float bestd = bound_f;
+  // Warm start inside one align: the correspondence of the previous linearisation (APD:164-180 ran one Gauss-Newton step ago) is
+  // an ordinary candidate -- its distance under the CURRENT pose is evaluated with the same expression as any other point -- and
+  // almost always the winner or within a few centimetres of it, so the branch-and-bound starts from a tight bound.  The answer is
+  // unchanged (the minimum over all candidates does not depend on the order they are met in); only the work is.
+  if (st->n_linearize > 0 && p < si.n) {
+    const int pc = pd.corr[si.orig[pq]];
+    if (pc >= 0 && pc < pd.tgt.n) {
+      const float d = sqdist3(qx, qy, qz, pd.tgt.x[pc], pd.tgt.y[pc], pd.tgt.z[pc]);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)pc;
+      if (key < best) {
+        best = key;
+        bestd = d;
+      }
+    }
+  }
   const int ng = (ti.n_tiles + 63) / 64;
   int g0 = (int)(((long)(blockIdx.x * 256 + (threadIdx.x & ~63)) * ng) / (si.n > 0 ? si.n : 1));
   g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);

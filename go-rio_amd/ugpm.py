@@ -49,50 +49,74 @@ def unpack(rec):
         d_delta_p_d_bw=rec[62:71].reshape(3, 3).copy(), d_delta_p_d_bv=rec[71:80].reshape(3, 3).copy(), d_delta_p_d_t=rec[80:83].copy())
 
 
+class UgpmBatch:
+    """A batch of windows marshalled once for gorio_ugpm_preint_batch (the struct array and the contiguous input arrays are kept
+    alive here).  run() is one call through the C ABI: everything on the device side, the host preparation of the library and
+    both transfers, happens inside it, every time."""
+
+    def __init__(self, windows, device=0, infer_t=None, type=UGPM, state_freq=50.0, correlate=True, overlap=8, quantum=-1.0, min_freq=500.0,
+                 gyr_bias=None, vel_bias=None, vel_bias_std=0.0, gyr_bias_std=0.0):
+        lib = load_library()
+        lib.gorio_ugpm_last_error.restype = C.c_char_p
+        n = len(windows)
+        self.n, self.device = n, int(device)
+        self.arr = (UgpmWindow * n)()
+        self.keep = []
+        self.counts = []
+        for i, w in enumerate(windows):
+            lib.gorio_ugpm_default_window(C.byref(self.arr[i]))
+            gt = np.ascontiguousarray(w["gyr_t"], np.float64)
+            g = np.ascontiguousarray(w["gyr"], np.float64)
+            vt = np.ascontiguousarray(w["vel_t"], np.float64)
+            v = np.ascontiguousarray(w["vel"], np.float64)
+            q = np.ascontiguousarray([w["end_t"]] if infer_t is None else infer_t[i], np.float64)
+            self.keep += [gt, g, vt, v, q]
+            a = self.arr[i]
+            a.gyr_t, a.gyr, a.n_gyr = _dp(gt), _dp(g), len(gt)
+            a.vel_t, a.vel, a.n_vel = _dp(vt), _dp(v), len(vt)
+            a.gyr_var, a.vel_var, a.start_t = w["gyr_var"], w["vel_var"], w["start_t"]
+            a.infer_t, a.n_infer = _dp(q), len(q)
+            a.type, a.min_freq, a.quantum, a.state_freq = int(type), min_freq, quantum, state_freq
+            a.correlate, a.overlap = int(bool(correlate)), int(overlap)
+            for k in range(3):
+                a.gyr_bias[k] = 0.0 if gyr_bias is None else float(gyr_bias[k])
+                a.vel_bias[k] = 0.0 if vel_bias is None else float(vel_bias[k])
+            a.vel_bias_std, a.gyr_bias_std = vel_bias_std, gyr_bias_std
+            self.counts.append(len(q))
+        self.out = np.zeros((sum(self.counts), REC))
+        self.diag = (UgpmDiag * n)()
+
+    def run(self):
+        """Returns the raw record array [sum(n_infer), 83] (see unpack)."""
+        lib = load_library()
+        rc = lib.gorio_ugpm_preint_batch(self.arr, self.n, C.c_void_p(_dp(self.out)), self.diag, self.device)
+        if rc < 0:
+            msg = lib.gorio_ugpm_last_error()
+            raise GorioError(rc, msg.decode() if msg else "")
+        return self.out
+
+    def results(self):
+        res, k = [], 0
+        for cnt in self.counts:
+            res.append([unpack(self.out[k + j]) for j in range(cnt)])
+            k += cnt
+        return res
+
+    def diagnostics(self):
+        return [dict(nb_state=d.nb_state, nb_gyr=d.nb_gyr, nb_vel=d.nb_vel, iters_rot=d.iters_rot, iters_vel=d.iters_vel, status=d.status,
+                     cost_rot=d.cost_rot, cost_vel=d.cost_vel, state_freq=d.state_freq) for d in self.diag]
+
+
 def ugpm_preint_batch(windows, device=0, infer_t=None, type=UGPM, state_freq=50.0, correlate=True, overlap=8, quantum=-1.0, min_freq=500.0,
                       gyr_bias=None, vel_bias=None, vel_bias_std=0.0, gyr_bias_std=0.0, return_diag=False):
     """gorio_ugpm_preint_batch over a list of window dicts (as made by synth.imu_window).  `infer_t`: None (each window's end_t) or a
     list of per-window arrays.  Returns a list (per window) of lists (per inference time) of PreintMeas dicts."""
-    lib = load_library()
-    lib.gorio_ugpm_last_error.restype = C.c_char_p
-    n = len(windows)
-    arr = (UgpmWindow * n)()
-    keep = []
-    counts = []
-    for i, w in enumerate(windows):
-        lib.gorio_ugpm_default_window(C.byref(arr[i]))
-        gt = np.ascontiguousarray(w["gyr_t"], np.float64)
-        g = np.ascontiguousarray(w["gyr"], np.float64)
-        vt = np.ascontiguousarray(w["vel_t"], np.float64)
-        v = np.ascontiguousarray(w["vel"], np.float64)
-        q = np.ascontiguousarray([w["end_t"]] if infer_t is None else infer_t[i], np.float64)
-        keep += [gt, g, vt, v, q]
-        a = arr[i]
-        a.gyr_t, a.gyr, a.n_gyr = _dp(gt), _dp(g), len(gt)
-        a.vel_t, a.vel, a.n_vel = _dp(vt), _dp(v), len(vt)
-        a.gyr_var, a.vel_var, a.start_t = w["gyr_var"], w["vel_var"], w["start_t"]
-        a.infer_t, a.n_infer = _dp(q), len(q)
-        a.type, a.min_freq, a.quantum, a.state_freq = int(type), min_freq, quantum, state_freq
-        a.correlate, a.overlap = int(bool(correlate)), int(overlap)
-        for k in range(3):
-            a.gyr_bias[k] = 0.0 if gyr_bias is None else float(gyr_bias[k])
-            a.vel_bias[k] = 0.0 if vel_bias is None else float(vel_bias[k])
-        a.vel_bias_std, a.gyr_bias_std = vel_bias_std, gyr_bias_std
-        counts.append(len(q))
-    out = np.zeros((sum(counts), REC))
-    diag = (UgpmDiag * n)()
-    rc = lib.gorio_ugpm_preint_batch(arr, n, C.c_void_p(_dp(out)), diag, int(device))
-    if rc < 0:
-        msg = lib.gorio_ugpm_last_error()
-        raise GorioError(rc, msg.decode() if msg else "")
-    res, k = [], 0
-    for cnt in counts:
-        res.append([unpack(out[k + j]) for j in range(cnt)])
-        k += cnt
+    b = UgpmBatch(windows, device=device, infer_t=infer_t, type=type, state_freq=state_freq, correlate=correlate, overlap=overlap, quantum=quantum,
+                  min_freq=min_freq, gyr_bias=gyr_bias, vel_bias=vel_bias, vel_bias_std=vel_bias_std, gyr_bias_std=gyr_bias_std)
+    b.run()
     if return_diag:
-        return res, [dict(nb_state=d.nb_state, nb_gyr=d.nb_gyr, nb_vel=d.nb_vel, iters_rot=d.iters_rot, iters_vel=d.iters_vel, status=d.status,
-                          cost_rot=d.cost_rot, cost_vel=d.cost_vel, state_freq=d.state_freq) for d in diag]
-    return res
+        return b.results(), b.diagnostics()
+    return b.results()
 
 
 def ugpm_stage_times():

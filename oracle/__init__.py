@@ -6,6 +6,7 @@ reference lines, and DESIGN.md for how the oracle is pinned.
 """
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 BUILD_DIR = os.path.join(_HERE, "build")
@@ -13,4 +14,4 @@ BUILD_DIR = os.path.join(_HERE, "build")
 
 def build(force: bool = False) -> None:
     """Compile the C/C++ restatements with the recipe in oracle/Makefile (gcc/g++ only, no GPU needed)."""
-    subprocess.check_call(["make", "-C", _HERE, "all"] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-C", _HERE, "all"] + (["-B"] if force else []), stdout=sys.stderr)  # stdout belongs to the caller (bench.py prints one JSON line)
