@@ -986,3 +986,14 @@ int gorio_apd_get_stage_times(gorio_apd_t* h, double seconds[4], int counts[4]) 
 }
 
 }  // extern "C"
+
+#ifdef GORIO_STATS
+extern "C" int gorio_debug_search_stats(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gorio::g_search_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gorio::g_search_stats), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

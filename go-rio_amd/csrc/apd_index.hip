@@ -278,6 +278,13 @@ __device__ __forceinline__ float lane_f(float v, int lane) { return __uint_as_fl
 // needs the tile are its 32 points fetched (wave-uniform scalar loads) and evaluated by all lanes.
 // visit order: 64-tile groups outward from `g0` (where near neighbours are expected) so the bound tightens early.
 
+#ifdef GORIO_STATS  // development statistics (never in the shipped build): work counters of the pruned searches
+__device__ unsigned long long g_search_stats[8];
+#define STAT_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_search_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define STAT_ADD(k, v) do { } while (0)
+#endif
+
 // 1-NN of every source point in the target, pruned.  One lane = one source point taken in MORTON order (a wave's 64 queries are
 // spatially compact).  grid: (ceil(n_spad_src / 256), splits, pairs), block 256.
 // Output: best_key[orig source index] = (float bits of d) << 32 | orig target index, exactly as nn_search_kernel.
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
       }
     }
   }
+  STAT_ADD(5, 1);
   const int ng = (ti.n_tiles + 63) / 64;
   int g0 = (int)(((long)(blockIdx.x * 256 + (threadIdx.x & ~63)) * ng) / (si.n > 0 ? si.n : 1));
   g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);
@@ -340,6 +348,8 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
       mask &= mask - 1;
       const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
       if (__ballot(box_bound(qx, qy, qz, bx) <= bestd) == 0) continue;
+      STAT_ADD(6, 1);
+      STAT_ADD(7, __builtin_popcountll(__ballot(box_bound(qx, qy, qz, bx) <= bestd)));
       const int j0 = (g * 64 + tlane) * 32;
 #pragma unroll
       for (int gg = 0; gg < 32; gg += 8) {
@@ -361,19 +371,16 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   }
 }
 
-// lexicographic (distance, original index) insertion into an ascending register list
+// Insertion of a packed key ((float bits of d) << 32 | original index; d >= 0, so the integer order IS the lexicographic
+// (distance, index) order) into an ascending register list: a compare and two 64-bit selects per slot.
 template <int K>
-__device__ __forceinline__ void topk_insert_lex(float (&bd)[K], int (&bi)[K], float cd, int ci) {
-  bool ins = false;
+__device__ __forceinline__ void topk_insert_key(unsigned long long (&L)[K], unsigned long long c) {
 #pragma unroll
   for (int t = 0; t < K; ++t) {
-    ins = ins || (cd < bd[t]) || (cd == bd[t] && ci < bi[t]);
-    const float td = bd[t];
-    const int tin = bi[t];
-    bd[t] = ins ? cd : td;
-    bi[t] = ins ? ci : tin;
-    cd = ins ? td : cd;
-    ci = ins ? tin : ci;
+    const bool lt = c < L[t];
+    const unsigned long long lo = lt ? c : L[t];
+    c = lt ? L[t] : c;
+    L[t] = lo;
   }
 }
 
@@ -396,13 +403,13 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restric
   const scalar_fp tz = as_scalar(si.sz);
   const scalar_ip to = (scalar_ip)si.orig;
   const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
-  float bd[K];
-  int bi[K];
+  __shared__ float s_d[32][256];  // distances of the current tile, one column per lane
+  STAT_ADD(0, 1);
+  const __attribute__((address_space(1))) int* og = (const __attribute__((address_space(1))) int*)si.orig;
+  unsigned long long L[K];  // ascending (distance, original index) keys
 #pragma unroll
-  for (int t = 0; t < K; ++t) {
-    bd[t] = INFINITY;
-    bi[t] = 0x7fffffff;
-  }
+  for (int t = 0; t < K; ++t) L[t] = 0x7f8000007fffffffull;  // (+inf, int max)
+  auto kth = [&]() -> float { return __uint_as_float((unsigned int)(L[K - 1] >> 32)); };
   const int ng = (si.n_tiles + 63) / 64;
   const int own_tile = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + (threadIdx.x & ~63)) / 32);
   const int g0 = own_tile / 64;
@@ -418,8 +425,9 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restric
     }
     // in the own group take the own tiles first (they fill the list with true neighbours), then the rest
     for (int phase = (g == g0 ? 0 : 1); phase < 2; ++phase) {
-      const float wb = wave_max(bd[K - 1]);
+      const float wb = wave_max(kth());
       unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= wb);
+      STAT_ADD(1, __builtin_popcountll(mask));
       if (g == g0) {
         const int ol = own_tile - g * 64;
         const unsigned long long near = (((ol + 3) >= 64) ? ~0ull : ((1ull << (ol + 3)) - 1ull)) & ~((ol >= 1) ? ((1ull << (ol - 1)) - 1ull) : 0ull);  // tiles ol-1 .. ol+2
@@ -429,8 +437,15 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restric
         const int tlane = __builtin_ctzll(mask);
         mask &= mask - 1;
         const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
-        if (__ballot(box_bound(qx, qy, qz, bx) <= bd[K - 1]) == 0) continue;
+        if (__ballot(box_bound(qx, qy, qz, bx) <= kth()) == 0) continue;
         const int j0 = (g * 64 + tlane) * 32;
+        // Pass 1 (every lane, no divergence): the 32 distances go to a lane-private LDS column and each lane marks the candidates
+        // that beat its current k-th key.  Pass 2: the wave inserts marked candidates one per lane per round -- max-over-lanes
+        // rounds instead of one (divergent, 20-step) insertion per candidate that ANY lane accepts.  The k smallest
+        // (distance, index) keys do not depend on the order of insertion, so the lists are unchanged.
+        STAT_ADD(2, 1);
+        const unsigned long long kkey = L[K - 1];
+        unsigned int marks = 0u;
 #pragma unroll
         for (int gg = 0; gg < 32; gg += 8) {
           float d[8];
@@ -438,14 +453,35 @@ __global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restric
           for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + gg + u], ty[j0 + gg + u], tz[j0 + gg + u]);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int oi = to[j0 + gg + u];
-            if (d[u] < bd[K - 1] || (d[u] == bd[K - 1] && oi < bi[K - 1])) topk_insert_lex<K>(bd, bi, d[u], oi);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d[u]) << 32) | (unsigned int)to[j0 + gg + u];
+            s_d[gg + u][threadIdx.x] = d[u];
+            if (key < kkey) marks |= 1u << (gg + u);
+          }
+        }
+        while (__ballot(marks != 0u)) {
+          STAT_ADD(3, 1);
+          if (marks != 0u) {
+            const int u = __builtin_ctz(marks);
+            marks &= marks - 1u;
+            const float cd = s_d[u][threadIdx.x];
+            const int ci = og[j0 + u];  // 32 consecutive ints of the tile: one cache line for the whole wave
+            const unsigned long long key = ((unsigned long long)__float_as_uint(cd) << 32) | (unsigned int)ci;
+            if (key < L[K - 1]) topk_insert_key<K>(L, key);
           }
         }
       }
     }
   }
-  if (p < n) covariance_from_list<K>(job, si.orig[p], bd, bi);  // lists never leave the registers: no partial lists, no second kernel
+  if (p < n) {
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      bd[t] = __uint_as_float((unsigned int)(L[t] >> 32));
+      bi[t] = (int)(unsigned int)(L[t] & 0xffffffffull);
+    }
+    covariance_from_list<K>(job, si.orig[p], bd, bi);
+  }  // lists never leave the registers: no partial lists, no second kernel
 }
 
 }  // namespace gorio
