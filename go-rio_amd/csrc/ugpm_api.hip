@@ -184,6 +184,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     }
     if (!made) UHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     // ata_kernel stages J through up to ~128 KB of dynamic LDS (the default limit is 64 KB)
+    UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::corr_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -339,10 +340,10 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     }
     {
       Stage st(c, 2);  // state correlation at the LPM-initialised state (a side thread in the reference, preint.h:939)
-      ug::corr_jac_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
+      ug::corr_jac_kernel<<<dim3(ug::kCorrJacParts, nw), 256, 0, c.stream>>>(c.d_wins);
       launch_ata(2);
       ug::corr_factor_kernel<<<nw, 512, 0, c.stream>>>(c.d_wins);
-      ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, nw), 256, sizeof(double) * 17 * 6 * max_S, c.stream>>>(c.d_wins);
+      ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, nw), 256, sizeof(double) * 17 * (6 * max_S + 16), c.stream>>>(c.d_wins);
     }
     std::vector<int> flags(kWinInts * (size_t)nw);
     for (int problem = 0; problem < 2; ++problem) {  // ceres::Solve #1 (rotation) and #2 (velocity), preint.h:943-967

@@ -1283,15 +1283,20 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
 }
 
 // Stacked Jacobian of the correlation step at the LPM-initialised state (preint.h:887-937): rows 3G (RotCost) + 3V (VelCost),
-// columns 6S = [rot channels | velocity channels].  grid: (windows), block 256.
+// columns 6S = [rot channels | velocity channels].  grid: (kCorrJacParts, windows), block 256: workgroup p owns every
+// kCorrJacParts-th gyro sample and velocity sample -- first the 3 x 6 / 3 x 3 factors of its samples (one lane per sample), then
+// the rows of those samples, one wave per (sample, axis) row with the lanes running along the S columns of a channel (coalesced
+// 512-byte stores, no index arithmetic beyond adds).
+constexpr int kCorrJacParts = 16;
 __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin w = load_win(wins, blockIdx.x);
+  const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0 || !w.correlate) return;
   const int S = w.S, G = w.G, V = w.V, n = 6 * S;
+  const int part = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* J = w.Jc;
-  for (size_t q = threadIdx.x; q < (size_t)(3 * G + 3 * V) * n; q += blockDim.x) J[q] = 0.0;
   const double wgt = sqrt(1.0 / w.vel_var);
-  for (int i = threadIdx.x; i < G; i += blockDim.x) {
+  // ---- gyro samples i = part, part + kCorrJacParts, ...
+  for (int i = part + kCorrJacParts * (int)threadIdx.x; i < G; i += kCorrJacParts * (int)blockDim.x) {
     double rot[3], drv[3];
     for (int c = 0; c < 3; ++c) {
       drv[c] = row_dot(w.KsKinv + ((size_t)c * G + i) * S, w.s_dr + (size_t)c * S, S);
@@ -1305,13 +1310,26 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
       for (int k = 0; k < 6; ++k) st[a * 6 + k] = D[a][k];
   }
   __syncthreads();
-  for (size_t q = threadIdx.x; q < (size_t)G * 9 * S; q += blockDim.x) {
-    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / (3 * S)) % 3), i = (int)(q / ((size_t)9 * S));
-    const double* st = w.sample_tmp + (size_t)i * 24;
-    J[((size_t)(3 * i + a)) * n + c * S + j] = st[a * 6 + c] * w.KsIntKinv[((size_t)c * G + i) * S + j] + st[a * 6 + c + 3] * w.KsKinv[((size_t)c * G + i) * S + j];
+  {
+    const int nmine = (G - part + kCorrJacParts - 1) / kCorrJacParts;  // samples of this part
+    for (int rr = wave; rr < nmine * 3; rr += 4) {                      // row = (sample, axis a)
+      const int i = part + kCorrJacParts * (rr / 3), a = rr % 3;
+      const double* st = w.sample_tmp + (size_t)i * 24;
+      double* row = J + (size_t)(3 * i + a) * n;
+      for (int c = 0; c < 3; ++c) {
+        const double f0 = st[a * 6 + c], f1 = st[a * 6 + c + 3];
+        const double* k0 = w.KsIntKinv + ((size_t)c * G + i) * S;
+        const double* k1 = w.KsKinv + ((size_t)c * G + i) * S;
+        for (int j = lane; j < S; j += 64) row[c * S + j] = f0 * k0[j] + f1 * k1[j];
+      }
+      for (int j = lane; j < 3 * S; j += 64) row[3 * S + j] = 0.0;  // a rotation residual does not see the velocity channels
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < V; i += blockDim.x) {  // cost_functions.h:350-377 with all six blocks
+  // ---- velocity samples (cost_functions.h:350-377 with all six blocks); sample_tmp is reused per sample index, and the gyro rows
+  // of THIS workgroup that read it are complete (barrier above); other workgroups touch other sample indices only when
+  // G and V samples with the same index belong to the same part, which they do (same i -> same part)
+  for (int i = part + kCorrJacParts * (int)threadIdx.x; i < V; i += kCorrJacParts * (int)blockDim.x) {
     const V3 rv = vel_rot_vec(w, i);
     const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
     double vel[3];
@@ -1323,12 +1341,22 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
     storeM(st + 9, RT);
   }
   __syncthreads();
-  for (size_t q = threadIdx.x; q < (size_t)V * 9 * S; q += blockDim.x) {
-    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / (3 * S)) % 3), i = (int)(q / ((size_t)9 * S));
-    const double* st = w.sample_tmp + (size_t)i * 24;
-    const size_t row = (size_t)(3 * G + 3 * i + a) * n;
-    J[row + c * S + j] = wgt * st[a * 3 + c] * w.KgyrIntKinv[((size_t)c * V + i) * S + j];
-    J[row + (3 + c) * S + j] = wgt * st[9 + a * 3 + c] * w.KvelKinv[((size_t)c * V + i) * S + j];
+  {
+    const int nmine = (V - part + kCorrJacParts - 1) / kCorrJacParts;
+    for (int rr = wave; rr < nmine * 3; rr += 4) {
+      const int i = part + kCorrJacParts * (rr / 3), a = rr % 3;
+      const double* st = w.sample_tmp + (size_t)i * 24;
+      double* row = J + (size_t)(3 * G + 3 * i + a) * n;
+      for (int c = 0; c < 3; ++c) {
+        const double f0 = wgt * st[a * 3 + c], f1 = wgt * st[9 + a * 3 + c];
+        const double* k0 = w.KgyrIntKinv + ((size_t)c * V + i) * S;
+        const double* k1 = w.KvelKinv + ((size_t)c * V + i) * S;
+        for (int j = lane; j < S; j += 64) {
+          row[c * S + j] = f0 * k0[j];
+          row[(3 + c) * S + j] = f1 * k1[j];
+        }
+      }
+    }
   }
 }
 
@@ -1744,35 +1772,88 @@ __global__ __launch_bounds__(512) void corr_factor_kernel(const UgpmWin* __restr
   }
 }
 
-// diag(A^-1) = column norms of L^-1, 16 columns per workgroup (4 per wave), unit right-hand sides in LDS; then
-// dsc = state_std / sqrt(diag(A^-1)) (preint.h:1487-1489).  grid: (ceil(6S / 16), windows), block 256.
+// diag(A^-1) = squared column norms of L^-1, 16 columns per workgroup; then dsc = state_std / sqrt(diag(A^-1)) (preint.h:1487-1489).
+// Blocked forward substitution L X = E_j with 16 right-hand sides: for block row i the update B_i = E_i - sum_k L_ik X_k runs on
+// the fp64 matrix cores (the k range is dealt to the 4 waves, operands: L straight from L2 -- the next block row is requested
+// while the current one is used -- and the X_k tiles from LDS), the 4 partial tiles are added in LDS in wave order, and one wave
+// solves the 16 x 16 triangular system for all 16 columns at once (lane = column, L_ii entries broadcast from LDS).
+// grid: (ceil(6S / 16), windows), block 256.  Dynamic LDS: (rows + 16) * 17 doubles for X, rows = 6 max_S.
 __global__ __launch_bounds__(256) void corr_diag_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0 || !w.correlate) return;
   const int n = 6 * w.S;
-  const int j0 = blockIdx.x * 16;
+  const int jb = blockIdx.x, j0 = jb * 16;
   if (j0 >= n) return;
-  extern __shared__ double Xc[];  // [n][17]
-  for (int q = threadIdx.x; q < n * 16; q += blockDim.x) {
-    const int i = q / 16, c = q % 16;
-    Xc[(size_t)i * 17 + c] = (i == j0 + c) ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (j0 + wv * 4 < n) {
-    wave_forward<4>(w.Ac, n, n, Xc + wv * 4, 17, j0 + wv * 4);
-    for (int c = 0; c < 4; ++c) {
-      const int col = j0 + wv * 4 + c;
-      if (col >= n) break;
-      double s = 0.0;
-      for (int i = col + lane; i < n; i += 64) {
-        const double v = Xc[(size_t)i * 17 + wv * 4 + c];
-        s += v * v;
-      }
+  const int nblk = (n + 15) / 16;
+  extern __shared__ double Xc[];            // X_k tiles: block k at Xc + (k - jb) * 16 * 17, element [r][c] at r * 17 + c
+  __shared__ double Pt[4][16][17];          // partial update tiles of the 4 waves
+  __shared__ double Dl[16][17];             // L_ii
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const double* Lm = w.Ac;
+  double ssq = 0.0;  // lanes 0..15 of wave 0: running sum of squares of column lane
+  // operand prefetch: for block row i, wave v owns k = jb + v, jb + v + 4, ...; element (row i*16 + lr, col k*16 + k0 + lk), k0 = 0,4,8,12
+  constexpr int KMAX = 16;  // blocks per wave per row: supports nblk - jb <= 64 (n <= 1024)
+  double la[KMAX][4];  // one buffer: the next block row is requested right after the matrix cores consumed the current one
+  auto fetch = [&](int i, double (&dst)[KMAX][4]) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-      if (lane == 0) w.dsc[col] = w.sstd[col] * (1.0 / sqrt(s));
+    for (int t = 0; t < KMAX; ++t) {
+      const int k = jb + wave + 4 * t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = i * 16 + lr, col = k * 16 + q * 4 + lk;
+        dst[t][q] = (k < i && row < n) ? Lm[(size_t)row * n + col] : 0.0;
+      }
     }
+  };
+  for (int i = jb; i < nblk; ++i) {
+    const int nb = min(16, n - i * 16);
+    // diagonal block of L to LDS (lower part; rows past n padded with the identity)
+    {
+      const int r = tid >> 4, c = tid & 15;
+      const int row = i * 16 + r, col = i * 16 + c;
+      Dl[r][c] = (c <= r && row < n) ? Lm[(size_t)row * n + col] : ((r == c) ? 1.0 : 0.0);
+    }
+    // partial update tile of this wave: sum over its k of L_ik X_k
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    if (i > jb) {
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) {
+        const int k = jb + wave + 4 * t;
+        if (k < i) {
+          const double* xk = Xc + (size_t)(k - jb) * 16 * 17;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[t][q], xk[(q * 4 + lk) * 17 + lr], acc, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) Pt[wave][lk + 4 * rg][lr] = acc[rg];
+    if (i + 1 < nblk) fetch(i + 1, la);  // lands while the triangular solve below runs
+    __syncthreads();
+    if (wave == 0 && lane < 16) {  // B_i = E_i - sum of partials (wave order), then L_ii X_i = B_i, column `lane`
+      const int c = lane;
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double bsum = ((Pt[0][r][c] + Pt[1][r][c]) + Pt[2][r][c]) + Pt[3][r][c];
+        double v = ((i == jb && r == c) ? 1.0 : 0.0) - bsum;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (q < r) v = __builtin_fma(-Dl[r][q], x[q], v);
+        v = v / Dl[r][r];
+        x[r] = (r < nb) ? v : 0.0;
+        ssq = __builtin_fma(x[r], x[r], ssq);
+      }
+      double* xi = Xc + (size_t)(i - jb) * 16 * 17;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xi[r * 17 + c] = x[r];
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && lane < 16) {
+    const int col = j0 + lane;
+    if (col < n) w.dsc[col] = w.sstd[col] * (1.0 / sqrt(ssq));
   }
 }
 
