@@ -8,7 +8,7 @@
 
 namespace gorio {
 
-constexpr int kAtaKSplit = 4;       // workgroups sharing the rows of J for one group of output tiles
+constexpr int kAtaKSplit = 2;       // workgroups sharing the rows of J for one group of output tiles
 constexpr int kAtaTilesPerGroup = 96;  // 16 x 16 output tiles per workgroup (8 waves x 12 accumulators)
 constexpr int kAtaMaxGroups = 28;
 constexpr int kWinInts = 48;        // ints per window: lmi[16], status at 16, ata_cnt at 20
