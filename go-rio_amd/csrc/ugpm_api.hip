@@ -357,9 +357,12 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
         if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
         else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
         ug::lm_decide_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
-        if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
-        else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
-        launch_ata(problem);
+        if (problem == 0) {
+          ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
+          launch_ata(problem);
+        } else {
+          ug::lm_relinearize_linear_kernel<<<dim3(nw, (3 * max_S + 63) / 64), 256, 0, c.stream>>>(c.d_wins);  // linear problem: J and J^T J stay exact
+        }
         if ((it & 1) == 1) {  // poll the done flags every other iteration
           UHIP(hipMemcpyAsync(flags.data(), c.d_ints, sizeof(int) * flags.size(), hipMemcpyDeviceToHost, c.stream));
           UHIP(hipStreamSynchronize(c.stream));

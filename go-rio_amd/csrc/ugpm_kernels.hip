@@ -1544,6 +1544,38 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
   CHOL_T(7);
 }
 
+// Problem #2 is LINEAR in its unknowns (the rotation states are constants there, so VelCost's Jacobian R(t)^T K_vel K^-1 and
+// the GpNorm blocks do not depend on x): after an accepted step the Jacobian and J^T J of the first evaluation are still exact,
+// the residual at the new point is the candidate residual already computed, and only the gradient g = J^T r changes.  This
+// kernel replaces the re-linearisation (vel_eval mode 1 + ata) for that problem with exactly those values.
+// grid: (windows, ceil(3 max_S / 64)), block 256 = 4 row slices x 64 columns.
+__global__ __launch_bounds__(256) void lm_relinearize_linear_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin w = load_win(wins, blockIdx.x);
+  if (*w.status != 0 || w.lmi[1] || !w.lmi[3]) return;
+  const int n = 3 * w.S, m = 3 * w.V + 3 * w.S;
+  const int j0 = blockIdx.y * 64;
+  if (j0 >= n) return;
+  const double* J = w.Jvel;
+  const double* rn = w.res_new;
+  __shared__ double sg[4][64];
+  if (blockIdx.y == 0)
+    for (int k = threadIdx.x; k < m; k += blockDim.x) w.res[k] = rn[k];
+  const int slice = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = j0 + lane;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (j < n) {
+    int k = slice;
+    for (; k + 12 < m; k += 16) {  // four independent chains keep four loads in flight
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += J[(size_t)(k + 4 * u) * n + j] * rn[k + 4 * u];
+    }
+    for (; k < m; k += 4) acc[0] += J[(size_t)k * n + j] * rn[k];
+  }
+  sg[slice][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (slice == 0 && j < n) w.lmv[j] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+}
+
 // =============================================================================================== Levenberg-Marquardt (Ceres 2.1 defaults + preint.h:943-948)
 // lmv layout (vectors of n = 3S): 0 g = J^T r (unscaled), 1 scale, 2 diag, 3 step (scaled), 4 delta (unscaled), 5 x, 6 x_new, 7 rhs
 // lmc: 0 cost, 1 cost_new, 2 radius, 3 decrease_factor, 4 x_norm, 5 model_cost_change, 6 step_norm, 7 initial cost
