@@ -356,7 +356,6 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
         ug::lm_step_kernel<<<nw, 512, 0, c.stream>>>(c.d_wins);
         if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
         else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
-        ug::lm_decide_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
         if (problem == 0) {
           ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
           launch_ata(problem);

@@ -1168,6 +1168,58 @@ __device__ __forceinline__ double row_dot(const double* __restrict__ row, const 
   return t;
 }
 
+// Acceptance test of a trust-region step (Ceres 2.1 TrustRegionMinimizer: tolerances of preint.h:943-948, rho > 1e-3, radius
+// update), evaluated from the candidate residuals res_new.  It is fused into the kernels that re-linearise after the step, whose
+// grid has several workgroups per window: EVERY workgroup evaluates the (deterministic) decision for itself from inputs none of
+// them writes (res_new, lmc[0], lmc[4..6], lmi[4]), and only the workgroup with commit == true stores the new solver state.
+// Returns 1 accepted, 0 rejected / invalid step, -1 terminated.  All threads of the workgroup must call it.
+__device__ int lm_decide_block(const UgpmWin& w, int m, int n, bool commit, double* sred /* [8] LDS */) {
+  if (!w.lmi[4]) {  // StepIsInvalid
+    if (commit && threadIdx.x == 0) {
+      w.lmc[2] = w.lmc[2] / w.lmc[3];
+      w.lmc[3] *= 2.0;
+      w.lmi[2] = 1;
+    }
+    return 0;
+  }
+  double c = 0.0;
+  for (int k = threadIdx.x; k < m; k += blockDim.x) c += w.res_new[k] * w.res_new[k];
+  const double cost_new = 0.5 * block_sum(c, sred);
+  const double cost = w.lmc[0];
+  const double cost_change = cost - cost_new;
+  int verdict;
+  double rho = 0.0;
+  if (w.lmc[6] <= 1e-8 * (w.lmc[4] + 1e-8)) verdict = -2;              // parameter_tolerance
+  else if (fabs(cost_change) <= 1e-10 * cost) verdict = -1;             // function_tolerance, preint.h:948
+  else {
+    rho = cost_change / w.lmc[5];
+    verdict = rho > 1e-3 ? 1 : 0;                                       // min_relative_decrease
+  }
+  __syncthreads();  // every thread has read the solver state before the committing workgroup's thread 0 rewrites it
+  if (commit) {
+    if (threadIdx.x == 0) {
+      w.lmc[1] = cost_new;
+      if (verdict < 0) {
+        w.lmi[1] = 1;
+        w.lmi[5] = verdict == -2 ? 2 : 1;
+      } else if (verdict == 1) {
+        w.lmi[6] += 1;
+        w.lmi[3] = 1;
+        w.lmc[2] = fmin(1e16, w.lmc[2] / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3)));
+        w.lmc[3] = 2.0;
+        w.lmi[2] = 0;
+      } else {
+        w.lmc[2] = w.lmc[2] / w.lmc[3];
+        w.lmc[3] *= 2.0;
+        w.lmi[2] = 1;
+      }
+    }
+    if (verdict == 1)
+      for (int j = threadIdx.x; j < n; j += blockDim.x) w.lmv[5 * (size_t)n + j] = w.lmv[6 * (size_t)n + j];
+  }
+  return verdict < 0 ? -1 : verdict;
+}
+
 // GpNorm residual rows [0, S) of channel block `blk` (cost_functions.h:47-57) and, once, its constant Jacobian block
 // J(r, c) = (KKinv - I)(c, r) w[r]  (cost_functions.h:36-42 as seen by the solver through the column-major map at :63-64)
 __device__ void gpnorm_rows(const UgpmWin& w, int ch, const double* __restrict__ s, double* __restrict__ res, double* __restrict__ J, int ldj, int col0, bool writeJ) {
@@ -1189,9 +1241,13 @@ __device__ void gpnorm_rows(const UgpmWin& w, int ch, const double* __restrict__
 __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict__ wins, int mode) {
   const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || w.lmi[1]) return;
-  if (mode == 1 && !w.lmi[3]) return;  // Jacobian only needed after an accepted step
   const int S = w.S, G = w.G, n = 3 * S;
-  const double* x = mode == 0 ? w.lmv + 6 * (size_t)n : w.lmv + 5 * (size_t)n;
+  __shared__ double sred[8];
+  if (mode == 1) {  // step acceptance (see lm_decide_block), then the Jacobian only after an accepted step -- at x_new, which is
+                    // what the committing workgroup is copying into x meanwhile
+    if (lm_decide_block(w, 3 * S + 3 * G, n, blockIdx.y == 0, sred) != 1) return;
+  }
+  const double* x = mode == 2 ? w.lmv + 5 * (size_t)n : w.lmv + 6 * (size_t)n;
   double* res = mode == 0 ? w.res_new : w.res;
   double* J = w.Jrot;
   const int i_lo = (int)(((long)G * blockIdx.y) / gridDim.y), i_hi = (int)(((long)G * (blockIdx.y + 1)) / gridDim.y);  // this workgroup's samples
@@ -1551,10 +1607,12 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
 // grid: (windows, ceil(3 max_S / 64)), block 256 = 4 row slices x 64 columns.
 __global__ __launch_bounds__(256) void lm_relinearize_linear_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin w = load_win(wins, blockIdx.x);
-  if (*w.status != 0 || w.lmi[1] || !w.lmi[3]) return;
+  if (*w.status != 0 || w.lmi[1]) return;
   const int n = 3 * w.S, m = 3 * w.V + 3 * w.S;
   const int j0 = blockIdx.y * 64;
   if (j0 >= n) return;
+  __shared__ double sred[8];
+  if (lm_decide_block(w, m, n, blockIdx.y == 0, sred) != 1) return;  // step acceptance, fused (see lm_decide_block)
   const double* J = w.Jvel;
   const double* rn = w.res_new;
   __shared__ double sg[4][64];
@@ -1722,57 +1780,6 @@ __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict_
   }
 }
 
-// After the candidate residuals: cost, tolerances, acceptance, radius update.  grid: (windows), block 256.
-__global__ __launch_bounds__(256) void lm_decide_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin w = load_win(wins, blockIdx.x);
-  if (*w.status != 0 || w.lmi[1]) return;
-  const int n = 3 * w.S;
-  const int problem = w.lmi[7];
-  const int m = problem == 0 ? 3 * w.S + 3 * w.G : 3 * w.V + 3 * w.S;
-  __shared__ double sred[8];
-  if (!w.lmi[4]) {  // StepIsInvalid
-    if (threadIdx.x == 0) {
-      w.lmc[2] = w.lmc[2] / w.lmc[3];
-      w.lmc[3] *= 2.0;
-      w.lmi[2] = 1;
-    }
-    return;
-  }
-  double c = 0.0;
-  for (int k = threadIdx.x; k < m; k += blockDim.x) c += w.res_new[k] * w.res_new[k];
-  const double cost_new = 0.5 * block_sum(c, sred);
-  const double cost = w.lmc[0];
-  int accept = 0;
-  if (threadIdx.x == 0) {
-    w.lmc[1] = cost_new;
-    const double cost_change = cost - cost_new;
-    if (w.lmc[6] <= 1e-8 * (w.lmc[4] + 1e-8)) {  // parameter_tolerance
-      w.lmi[1] = 1;
-      w.lmi[5] = 2;
-    } else if (fabs(cost_change) <= 1e-10 * cost) {  // function_tolerance, preint.h:948
-      w.lmi[1] = 1;
-      w.lmi[5] = 1;
-    } else {
-      const double rho = cost_change / w.lmc[5];
-      if (rho > 1e-3) {  // min_relative_decrease
-        accept = 1;
-        w.lmi[6] += 1;
-        w.lmi[3] = 1;
-        w.lmc[2] = fmin(1e16, w.lmc[2] / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3)));
-        w.lmc[3] = 2.0;
-        w.lmi[2] = 0;
-      } else {
-        w.lmc[2] = w.lmc[2] / w.lmc[3];
-        w.lmc[3] *= 2.0;
-        w.lmi[2] = 1;
-      }
-    }
-    sred[7] = (double)accept;
-  }
-  __syncthreads();
-  if (sred[7] != 0.0)
-    for (int j = threadIdx.x; j < n; j += blockDim.x) w.lmv[5 * (size_t)n + j] = w.lmv[6 * (size_t)n + j];
-}
 
 // write the solution back into the state.  grid: (windows), block 256.
 __global__ __launch_bounds__(256) void lm_end_kernel(const UgpmWin* __restrict__ wins, int problem, double* __restrict__ diag_out /* [windows][4] */) {
