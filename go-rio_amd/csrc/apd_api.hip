@@ -338,6 +338,7 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
       bitonic_tile_merge_kernel<<<dim3(max_pow2 / kSortTile, nj), 1024, 0, lead->stream>>>(dj, k);
     }
     gather_sorted_kernel<<<dim3((max_spad + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
+    kd_refine_kernel<<<dim3((max_spad + kKdChunk - 1) / kKdChunk, nj), 1024, 0, lead->stream>>>(dj);
     box_tile_kernel<<<dim3((max_spad / 32 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
     box_super_kernel<<<dim3((max_spad / 512 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
   }
