@@ -89,21 +89,7 @@ hipStream_t device_stream(int device) {
   std::lock_guard<std::mutex> lock(mu);
   if ((int)streams.size() <= device) streams.resize(device + 1, nullptr);
   if (!streams[device]) {
-    // GORIO_CU_SPLIT=k (1..7): reserve k/8 of the CUs for the UGPM stream and keep this stream off them, so that scan matching and
-    // GP pre-integration running side by side do not queue behind each other's workgroups (hipExtStreamCreateWithCUMask).
-    const char* split = std::getenv("GORIO_CU_SPLIT");
-    const int k = split ? std::atoi(split) : 0;
-    bool made = false;
-    if (k >= 1 && k <= 7) {
-      uint32_t mask[8];
-      for (int w = 0; w < 8; ++w) {
-        mask[w] = 0;
-        for (int b = 0; b < 32; ++b)
-          if (((w * 32 + b) % 8) >= k) mask[w] |= (1u << b);
-      }
-      made = hipExtStreamCreateWithCUMask(&streams[device], 8, mask) == hipSuccess;
-    }
-    if (!made && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) return nullptr;
   }
   return streams[device];
 }

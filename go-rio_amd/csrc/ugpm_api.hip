@@ -166,18 +166,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     hipFree(c.ws); hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag);
     c = Ctx();
     c.device = device;
-    const char* split = std::getenv("GORIO_CU_SPLIT");  // see apd_api.hip: this stream gets the reserved k/8 of the CUs
-    const int k = split ? std::atoi(split) : 0;
     bool made = false;
-    if (k >= 1 && k <= 7) {
-      uint32_t mask[8];
-      for (int w = 0; w < 8; ++w) {
-        mask[w] = 0;
-        for (int b = 0; b < 32; ++b)
-          if (((w * 32 + b) % 8) < k) mask[w] |= (1u << b);
-      }
-      made = hipExtStreamCreateWithCUMask(&c.stream, 8, mask) == hipSuccess;
-    }
     if (!made) {  // highest priority: these are many small latency-bound launches that should not queue behind the scan matcher's large grids
       int lo = 0, hi = 0;
       if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi) == hipSuccess) made = true;
