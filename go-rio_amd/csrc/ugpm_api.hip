@@ -174,6 +174,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     if (!made) UHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     // ata_kernel stages J through up to ~128 KB of dynamic LDS (the default limit is 64 KB)
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::corr_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::infer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (6 * 160 + 16) * 8) /* S = 160: with the 31 KB of static LDS this is just inside the 160 KB of a CU */);
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -364,7 +365,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     {
       Stage st(c, 4);
       ug::finish_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
-      ug::infer_kernel<<<dim3(std::max(1, max_infer), nw), 256, sizeof(double) * 7 * 6 * max_S, c.stream>>>(c.d_wins);
+      ug::infer_kernel<<<dim3(std::max(1, max_infer), nw), 256, sizeof(double) * 17 * (6 * max_S + 16), c.stream>>>(c.d_wins);
     }
     UHIP(hipGetLastError());
   }

@@ -1811,49 +1811,42 @@ __global__ __launch_bounds__(512) void corr_factor_kernel(const UgpmWin* __restr
   }
 }
 
-// diag(A^-1) = squared column norms of L^-1, 16 columns per workgroup; then dsc = state_std / sqrt(diag(A^-1)) (preint.h:1487-1489).
-// Blocked forward substitution L X = E_j with 16 right-hand sides: for block row i the update B_i = E_i - sum_k L_ik X_k runs on
-// the fp64 matrix cores (the k range is dealt to the 4 waves, operands: L straight from L2 -- the next block row is requested
-// while the current one is used -- and the X_k tiles from LDS), the 4 partial tiles are added in LDS in wave order, and one wave
-// solves the 16 x 16 triangular system for all 16 columns at once (lane = column, L_ii entries broadcast from LDS).
-// grid: (ceil(6S / 16), windows), block 256.  Dynamic LDS: (rows + 16) * 17 doubles for X, rows = 6 max_S.
-__global__ __launch_bounds__(256) void corr_diag_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin w = load_win(wins, blockIdx.y);
-  if (*w.status != 0 || !w.correlate) return;
-  const int n = 6 * w.S;
-  const int jb = blockIdx.x, j0 = jb * 16;
-  if (j0 >= n) return;
+// Blocked forward substitution L X = B for 16 right-hand-side columns by one workgroup of 256 threads, block rows jb .. nblk-1
+// (B is zero above block row jb).  For block row i the update B_i - sum_k L_ik X_k runs on the fp64 matrix cores (the k range is
+// dealt to the 4 waves; operands: L straight from L2 -- the next block row is requested while the triangular solve of the current
+// one runs -- and the X_k tiles from LDS), the 4 partial tiles are added in LDS in wave order, and one wave solves the 16 x 16
+// triangular system for all 16 columns at once (lane = column, L_ii entries broadcast from LDS).
+// X_k lands in Xc + (k - jb) * 16 * 17 as [r][c] at r * 17 + c; rows past n are zero.  On entry Xc holds B in the same layout
+// (the caller fills it with all lanes; a barrier is taken here before it is read).
+struct Solve16Lds {
+  double Pt[4][16][17];  // partial update tiles of the 4 waves
+  double Dl[16][17];     // L_ii
+};
+__device__ __forceinline__ void blocked_lower_solve16(const double* __restrict__ Lm, int n, int jb, double* __restrict__ Xc, Solve16Lds& sh) {
   const int nblk = (n + 15) / 16;
-  extern __shared__ double Xc[];            // X_k tiles: block k at Xc + (k - jb) * 16 * 17, element [r][c] at r * 17 + c
-  __shared__ double Pt[4][16][17];          // partial update tiles of the 4 waves
-  __shared__ double Dl[16][17];             // L_ii
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  const double* Lm = w.Ac;
-  double ssq = 0.0;  // lanes 0..15 of wave 0: running sum of squares of column lane
   // operand prefetch: for block row i, wave v owns k = jb + v, jb + v + 4, ...; element (row i*16 + lr, col k*16 + k0 + lk), k0 = 0,4,8,12
   constexpr int KMAX = 16;  // blocks per wave per row: supports nblk - jb <= 64 (n <= 1024)
-  double la[KMAX][4];  // one buffer: the next block row is requested right after the matrix cores consumed the current one
-  auto fetch = [&](int i, double (&dst)[KMAX][4]) {
+  double la[KMAX][4];       // one buffer: the next block row is requested right after the matrix cores consumed the current one
+  auto fetch = [&](int i) {
 #pragma unroll
     for (int t = 0; t < KMAX; ++t) {
       const int k = jb + wave + 4 * t;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = i * 16 + lr, col = k * 16 + q * 4 + lk;
-        dst[t][q] = (k < i && row < n) ? Lm[(size_t)row * n + col] : 0.0;
+        la[t][q] = (k < i && row < n) ? Lm[(size_t)row * n + col] : 0.0;
       }
     }
   };
   for (int i = jb; i < nblk; ++i) {
     const int nb = min(16, n - i * 16);
-    // diagonal block of L to LDS (lower part; rows past n padded with the identity)
-    {
+    {  // diagonal block of L to LDS (lower part; rows past n padded with the identity)
       const int r = tid >> 4, c = tid & 15;
       const int row = i * 16 + r, col = i * 16 + c;
-      Dl[r][c] = (c <= r && row < n) ? Lm[(size_t)row * n + col] : ((r == c) ? 1.0 : 0.0);
+      sh.Dl[r][c] = (c <= r && row < n) ? Lm[(size_t)row * n + col] : ((r == c) ? 1.0 : 0.0);
     }
-    // partial update tile of this wave: sum over its k of L_ik X_k
     f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
     if (i > jb) {
 #pragma unroll
@@ -1867,31 +1860,50 @@ __global__ __launch_bounds__(256) void corr_diag_kernel(const UgpmWin* __restric
       }
     }
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) Pt[wave][lk + 4 * rg][lr] = acc[rg];
-    if (i + 1 < nblk) fetch(i + 1, la);  // lands while the triangular solve below runs
+    for (int rg = 0; rg < 4; ++rg) sh.Pt[wave][lk + 4 * rg][lr] = acc[rg];
+    if (i + 1 < nblk) fetch(i + 1);  // lands while the triangular solve below runs
     __syncthreads();
-    if (wave == 0 && lane < 16) {  // B_i = E_i - sum of partials (wave order), then L_ii X_i = B_i, column `lane`
+    if (wave == 0 && lane < 16) {  // B_i - sum of partials (wave order), then L_ii X_i = ., column `lane`
       const int c = lane;
       double x[16];
+      double* xi = Xc + (size_t)(i - jb) * 16 * 17;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        double bsum = ((Pt[0][r][c] + Pt[1][r][c]) + Pt[2][r][c]) + Pt[3][r][c];
-        double v = ((i == jb && r == c) ? 1.0 : 0.0) - bsum;
+        const double bsum = ((sh.Pt[0][r][c] + sh.Pt[1][r][c]) + sh.Pt[2][r][c]) + sh.Pt[3][r][c];
+        double v = xi[r * 17 + c] - bsum;
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-          if (q < r) v = __builtin_fma(-Dl[r][q], x[q], v);
-        v = v / Dl[r][r];
+          if (q < r) v = __builtin_fma(-sh.Dl[r][q], x[q], v);
+        v = v / sh.Dl[r][r];
         x[r] = (r < nb) ? v : 0.0;
-        ssq = __builtin_fma(x[r], x[r], ssq);
       }
-      double* xi = Xc + (size_t)(i - jb) * 16 * 17;
 #pragma unroll
       for (int r = 0; r < 16; ++r) xi[r * 17 + c] = x[r];
     }
     __syncthreads();
   }
-  if (wave == 0 && lane < 16) {
-    const int col = j0 + lane;
+}
+
+// diag(A^-1) = squared column norms of L^-1, 16 columns per workgroup; then dsc = state_std / sqrt(diag(A^-1)) (preint.h:1487-1489).
+// grid: (ceil(6S / 16), windows), block 256.  Dynamic LDS: (rows + 16) * 17 doubles for X, rows = 6 max_S.
+__global__ __launch_bounds__(256) void corr_diag_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin w = load_win(wins, blockIdx.y);
+  if (*w.status != 0 || !w.correlate) return;
+  const int n = 6 * w.S;
+  const int jb = blockIdx.x, j0 = jb * 16;
+  if (j0 >= n) return;
+  extern __shared__ double Xc[];
+  __shared__ Solve16Lds sh;
+  {
+    const int rows = ((n + 15) / 16 - jb) * 16;
+    for (int q = threadIdx.x; q < rows * 16; q += blockDim.x) Xc[(size_t)(q >> 4) * 17 + (q & 15)] = (q >> 4) == (q & 15) ? 1.0 : 0.0;  // E_j
+  }
+  blocked_lower_solve16(w.Ac, n, jb, Xc, sh);
+  if (threadIdx.x < 16) {
+    const int c = threadIdx.x, col = j0 + c;
+    const int rows = ((n + 15) / 16 - jb) * 16;
+    double ssq = 0.0;
+    for (int r = 0; r < rows; ++r) ssq = __builtin_fma(Xc[(size_t)r * 17 + c], Xc[(size_t)r * 17 + c], ssq);
     if (col < n) w.dsc[col] = w.sstd[col] * (1.0 / sqrt(ssq));
   }
 }
@@ -1978,81 +1990,98 @@ __global__ __launch_bounds__(256) void infer_kernel(const UgpmWin* __restrict__ 
   }
   const int S = w.S, n = 6 * S;
   const double t = w.infer_t[qi], dt = t - w.start_t;
+  __shared__ double ksv[6][160];  // ks = k_int(start, t, state_t) per channel (each value is used S times below: evaluated once)
+  __shared__ double ksd[3][160];  // d ks / dt of the velocity channels
   __shared__ double ksK[6][160];  // ks K^-1 per channel
-  __shared__ double sval[6][8];   // per channel: 0 ks.alpha, 1 ks K^-1 ks^T, 2 d_r_dt / (ks_dt.alpha + ksK.d_vel_dt), 3..5 d/d bw, 6..8 -> second array
-  __shared__ double sval2[6][4];
+  __shared__ double sval[6][8];   // per channel: 0 ks.alpha, 1 ks K^-1 ks^T, 2 d_r_dt / (ks_dt.alpha + ksK.d_vel_dt), 3..5 d/d bw
+  __shared__ double sval2[6][4];  // d/d bv
   __shared__ double sred[8];
   __shared__ double scov[36];
   for (int q = threadIdx.x; q < 6 * S; q += blockDim.x) {
-    const int c = q / S, j = q % S;
+    const int c = q / S, j = q - c * S;
+    ksv[c][j] = se_kint(w.start_t, t, w.state_t[j], w.hyper[c * 4], w.hyper[c * 4 + 1]);
+    if (c >= 3) ksd[c - 3][j] = se_kint_dt(w.start_t, t, w.state_t[j], w.hyper[c * 4], w.hyper[c * 4 + 1]);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < 6 * S; q += blockDim.x) {
+    const int c = q / S, j = q - c * S;
+    const double* Kc = w.Kinv + (size_t)c * S * S + j;
     double s = 0.0;
-    for (int k = 0; k < S; ++k) s += se_kint(w.start_t, t, w.state_t[k], w.hyper[c * 4], w.hyper[c * 4 + 1]) * w.Kinv[((size_t)c * S + k) * S + j];
+    for (int k = 0; k < S; ++k) s += ksv[c][k] * Kc[(size_t)k * S];
     ksK[c][j] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
-    const int c = threadIdx.x;
-    const double l2 = w.hyper[c * 4], sf2 = w.hyper[c * 4 + 1];
-    double ka = 0.0, kKk = 0.0, e2 = 0.0, bw[3] = {0, 0, 0}, bv[3] = {0, 0, 0};
-    for (int j = 0; j < S; ++j) {
-      const double ks = se_kint(w.start_t, t, w.state_t[j], l2, sf2);
-      ka += ks * w.alpha[c * S + j];
-      kKk += ksK[c][j] * ks;
-      if (c < 3) {
-        e2 += ksK[c][j] * w.d_d_r_dt[c * S + j];
-        for (int q = 0; q < 3; ++q) bw[q] += ksK[c][j] * w.d_state_bw[((size_t)c * S + j) * 3 + q];
-      } else {
-        e2 += se_kint_dt(w.start_t, t, w.state_t[j], l2, sf2) * w.alpha[c * S + j] + ksK[c][j] * w.d_vel_dt[(c - 3) * S + j];
+  {  // per-channel contractions over the S states: one wave per channel (lanes along j), nine sums each
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wv; c < 6; c += (int)(blockDim.x >> 6)) {
+      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // ka, kKk, e2, bw[3], bv[3]
+      for (int j = lane; j < S; j += 64) {
+        const double ks = ksv[c][j], kk = ksK[c][j];
+        acc[0] += ks * w.alpha[c * S + j];
+        acc[1] += kk * ks;
+        if (c < 3) {
+          acc[2] += kk * w.d_d_r_dt[c * S + j];
+          for (int q = 0; q < 3; ++q) acc[3 + q] += kk * w.d_state_bw[((size_t)c * S + j) * 3 + q];
+        } else {
+          acc[2] += ksd[c - 3][j] * w.alpha[c * S + j] + kk * w.d_vel_dt[(c - 3) * S + j];
+          for (int q = 0; q < 3; ++q) {
+            acc[3 + q] += kk * w.d_vel_bw[((size_t)(c - 3) * S + j) * 3 + q];
+            acc[6 + q] += kk * w.d_vel_bv[((size_t)(c - 3) * S + j) * 3 + q];
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 9; ++v)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[v] += __shfl_down(acc[v], off, 64);
+      if (lane == 0) {
+        const double l2 = w.hyper[c * 4], sf2 = w.hyper[c * 4 + 1];
+        double var = kss_int(w.start_t, t, l2, sf2) - acc[1];
+        if (var <= 0) var = dt * dt * w.hyper[c * 4 + 2];
+        sval[c][0] = acc[0] + dt * w.hyper[c * 4 + 3];
+        sval[c][1] = var;
+        sval[c][2] = acc[2];
         for (int q = 0; q < 3; ++q) {
-          bw[q] += ksK[c][j] * w.d_vel_bw[((size_t)(c - 3) * S + j) * 3 + q];
-          bv[q] += ksK[c][j] * w.d_vel_bv[((size_t)(c - 3) * S + j) * 3 + q];
+          sval[c][3 + q] = acc[3 + q];
+          sval2[c][q] = acc[6 + q];
         }
       }
     }
-    double var = kss_int(w.start_t, t, l2, sf2) - kKk;
-    if (var <= 0) var = dt * dt * w.hyper[c * 4 + 2];
-    sval[c][0] = ka + dt * w.hyper[c * 4 + 3];
-    sval[c][1] = var;
-    sval[c][2] = e2;
-    for (int q = 0; q < 3; ++q) {
-      sval[c][3 + q] = bw[q];
-      sval2[c][q] = bv[q];
-    }
   }
   __syncthreads();
-  // covariance: cov_ab = ks_a C_ab ks_b^T with C = D A^-1 D  =>  (L^-1 u_a) . (L^-1 u_b), u_a = dsc .* ksK_a placed in block a
+  // covariance: cov_ab = ks_a C_ab ks_b^T with C = D A^-1 D  =>  (L^-1 u_a) . (L^-1 u_b), u_a = dsc .* ksK_a placed in block a:
+  // one blocked forward substitution with the six u_a as right-hand-side columns (blocked_lower_solve16)
   if (w.correlate) {
-    extern __shared__ double Yc[];  // [n][7]: columns = L^-1 u_a
-    for (int q = threadIdx.x; q < n * 6; q += blockDim.x) {
-      const int i = q / 6, a = q % 6;
-      Yc[(size_t)i * 7 + a] = (i / S == a) ? w.dsc[i] * ksK[a][i - a * S] : 0.0;
-    }
+    extern __shared__ double Xc[];  // [ceil16(n)][17]: columns 0..5 = L^-1 u_a
+    __shared__ Solve16Lds sh;
+    const int rows = ((n + 15) / 16) * 16;
+    for (int q = threadIdx.x; q < rows * 16; q += blockDim.x) Xc[(size_t)(q >> 4) * 17 + (q & 15)] = 0.0;
     __syncthreads();
-    {
-      const int wv = threadIdx.x >> 6;
-      if (wv < 3) wave_forward<2>(w.Ac, n, n, Yc + wv * 2, 7, wv * 2 * S);  // u_a is zero above row a S
+    for (int row = threadIdx.x; row < n; row += blockDim.x) {
+      const int c = row / S;
+      Xc[(size_t)row * 17 + c] = w.dsc[row] * ksK[c][row - c * S];
     }
-    __syncthreads();
+    blocked_lower_solve16(w.Ac, n, 0, Xc, sh);
     for (int pair = 0; pair < 21; ++pair) {
-      int a = 0, b = pair;
-      while (b >= 6 - a) { b -= 6 - a; ++a; }
-      b += a;
+      int a2 = 0, b2 = pair;
+      while (b2 >= 6 - a2) { b2 -= 6 - a2; ++a2; }
+      b2 += a2;
       double acc = 0.0;
-      for (int k = threadIdx.x; k < n; k += blockDim.x) acc += Yc[(size_t)k * 7 + a] * Yc[(size_t)k * 7 + b];
+      for (int k = threadIdx.x; k < rows; k += blockDim.x) acc += Xc[(size_t)k * 17 + a2] * Xc[(size_t)k * 17 + b2];
       acc = block_sum(acc, sred);
       if (threadIdx.x == 0) {
-        scov[a * 6 + b] = acc;
-        scov[b * 6 + a] = acc;
+        scov[a2 * 6 + b2] = acc;
+        scov[b2 * 6 + a2] = acc;
       }
     }
   } else {
     if (threadIdx.x < 36) scov[threadIdx.x] = 0.0;
     __syncthreads();
     if (threadIdx.x < 6) {
-      const int a = threadIdx.x;
-      double s = 0.0;
-      for (int j = 0; j < S; ++j) s += ksK[a][j] * w.var[a * S + j] * ksK[a][j];
-      scov[a * 6 + a] = s;
+      const int a2 = threadIdx.x;
+      double s2 = 0.0;
+      for (int j = 0; j < S; ++j) s2 += ksK[a2][j] * w.var[a2 * S + j] * ksK[a2][j];
+      scov[a2 * 6 + a2] = s2;
     }
   }
   __syncthreads();
