@@ -1010,9 +1010,141 @@ __device__ __forceinline__ double block_max(double v, double* sred) {
   return t;
 }
 
+// Blocked forward substitution L X = B for 16 right-hand-side columns by one workgroup of 256 threads, block rows jb .. nblk-1
+// (B is zero above block row jb).  For block row i the update B_i - sum_k L_ik X_k runs on the fp64 matrix cores (the k range is
+// dealt to the 4 waves; operands: L straight from L2 -- the next block row is requested while the triangular solve of the current
+// one runs -- and the X_k tiles from LDS), the 4 partial tiles are added in LDS in wave order, and one wave solves the 16 x 16
+// triangular system for all 16 columns at once (lane = column, L_ii entries broadcast from LDS).
+// X_k lands in Xc + (k - jb) * 16 * 17 as [r][c] at r * 17 + c; rows past n are zero.  On entry Xc holds B in the same layout
+// (the caller fills it with all lanes; a barrier is taken here before it is read).
+struct Solve16Lds {
+  double Pt[4][16][17];  // partial update tiles of the 4 waves
+  double Dl[16][17];     // L_ii
+};
+__device__ __forceinline__ void blocked_lower_solve16(const double* __restrict__ Lm, int n, int jb, double* __restrict__ Xc, Solve16Lds& sh) {
+  const int nblk = (n + 15) / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  // operand prefetch: for block row i, wave v owns k = jb + v, jb + v + 4, ...; element (row i*16 + lr, col k*16 + k0 + lk), k0 = 0,4,8,12
+  constexpr int KMAX = 16;  // blocks per wave per row: supports nblk - jb <= 64 (n <= 1024)
+  double la[KMAX][4];       // one buffer: the next block row is requested right after the matrix cores consumed the current one
+  auto fetch = [&](int i) {
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) {
+      const int k = jb + wave + 4 * t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = i * 16 + lr, col = k * 16 + q * 4 + lk;
+        la[t][q] = (k < i && row < n) ? Lm[(size_t)row * n + col] : 0.0;
+      }
+    }
+  };
+  for (int i = jb; i < nblk; ++i) {
+    const int nb = min(16, n - i * 16);
+    {  // diagonal block of L to LDS (lower part; rows past n padded with the identity)
+      const int r = tid >> 4, c = tid & 15;
+      const int row = i * 16 + r, col = i * 16 + c;
+      sh.Dl[r][c] = (c <= r && row < n) ? Lm[(size_t)row * n + col] : ((r == c) ? 1.0 : 0.0);
+    }
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    if (i > jb) {
+#pragma unroll
+      for (int t = 0; t < KMAX; ++t) {
+        const int k = jb + wave + 4 * t;
+        if (k < i) {
+          const double* xk = Xc + (size_t)(k - jb) * 16 * 17;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[t][q], xk[(q * 4 + lk) * 17 + lr], acc, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) sh.Pt[wave][lk + 4 * rg][lr] = acc[rg];
+    if (i + 1 < nblk) fetch(i + 1);  // lands while the triangular solve below runs
+    __syncthreads();
+    if (wave == 0 && lane < 16) {  // B_i - sum of partials (wave order), then L_ii X_i = ., column `lane`
+      const int c = lane;
+      double x[16];
+      double* xi = Xc + (size_t)(i - jb) * 16 * 17;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const double bsum = ((sh.Pt[0][r][c] + sh.Pt[1][r][c]) + sh.Pt[2][r][c]) + sh.Pt[3][r][c];
+        double v = xi[r * 17 + c] - bsum;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (q < r) v = __builtin_fma(-sh.Dl[r][q], x[q], v);
+        v = v / sh.Dl[r][r];
+        x[r] = (r < nb) ? v : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xi[r * 17 + c] = x[r];
+    }
+    __syncthreads();
+  }
+}
+
 // =============================================================================================== Gram stage
 
-// grid: (6 channels, windows), block 256.  preint.h:832-866 for one channel.
+// Small dense products on the fp64 matrix cores for S x S matrices resident in L2 (S <= 160), 16 x 16 output tiles dealt to
+// the waves of the workgroup, operands read straight from global memory (for every k-step of 4 a lane supplies one element of
+// each operand; the loop is unrolled so several steps of loads are in flight).  Result layout of v_mfma_f64_16x16x4_f64:
+// col = lane & 15, row = (lane >> 4) + 4 reg.
+//   small_gemm_tn_sym: C = B^T B for a LOWER-triangular B (B[k][i] = 0 for k < i): only k >= the tile's row block contributes;
+//                      lower tiles are computed and mirrored.
+//   small_gemm_nn:     C = A B.
+__device__ __forceinline__ void small_gemm_tn_sym(const double* __restrict__ B, double* __restrict__ C, int S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (int)(blockDim.x >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int T = (S + 15) / 16;
+  for (int q = wave; q < T * (T + 1) / 2; q += nwave) {
+    int tr = (int)((sqrtf(8.0f * (float)q + 1.0f) - 1.0f) * 0.5f);
+    while (tr * (tr + 1) / 2 > q) --tr;
+    while ((tr + 1) * (tr + 2) / 2 <= q) ++tr;
+    const int tc = q - tr * (tr + 1) / 2;
+    const int i = tr * 16 + lr, j = tc * 16 + lr;
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = tr * 16; k0 < S; k0 += 4) {
+      const int k = k0 + lk;
+      const double av = (k < S && i < S) ? B[(size_t)k * S + i] : 0.0;
+      const double bv = (k < S && j < S) ? B[(size_t)k * S + j] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int r = tr * 16 + lk + 4 * rg, c = tc * 16 + lr;
+      if (r < S && c < S) {
+        C[(size_t)r * S + c] = acc[rg];
+        C[(size_t)c * S + r] = acc[rg];
+      }
+    }
+  }
+}
+__device__ __forceinline__ void small_gemm_nn(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = (int)(blockDim.x >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int T = (S + 15) / 16;
+  for (int q = wave; q < T * T; q += nwave) {
+    const int ti = q / T, tj = q - ti * T;
+    const int i = ti * 16 + lr, j = tj * 16 + lr;
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < S; k0 += 4) {
+      const int k = k0 + lk;
+      const double av = (k < S && i < S) ? A[(size_t)i * S + k] : 0.0;
+      const double bv = (k < S && j < S) ? B[(size_t)k * S + j] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int r = ti * 16 + lk + 4 * rg, c = tj * 16 + lr;
+      if (r < S && c < S) C[(size_t)r * S + c] = acc[rg];
+    }
+  }
+}
+
+// grid: (6 channels, windows), block 256.  preint.h:832-866 for one channel: K + sz2 I = L L^T (block_cholesky), L^-1 by the
+// blocked 16-column forward substitution, K^-1 = L^-T L^-1, K K^-1 and K_int K^-1 on the matrix cores.
 __global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0) return;
@@ -1020,78 +1152,65 @@ __global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ w
   const double l2 = w.hyper[c * 4 + 0], sf2 = w.hyper[c * 4 + 1], sz2 = w.hyper[c * 4 + 2];
   double* A = w.Kinv + (size_t)c * S * S;    // K + sz2 I -> L -> finally K^-1
   double* B = w.KKinv + (size_t)c * S * S;   // L^-1 scratch -> finally K K^-1
+  double* Kc = w.JtJ + (size_t)c * S * S;    // scratch: the Gram matrix itself (JtJ / lhs are idle until the LM stage, 9 S^2 each)
   const double* st = w.state_t;
   __shared__ int sflag;
   __shared__ CholLds chol;
-  for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
-    const int i = q / S, j = q % S;
-    A[q] = se_k(st[i], st[j], l2, sf2) + (i == j ? sz2 : 0.0);
-  }
+  __shared__ Solve16Lds sh;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (int)(blockDim.x >> 6);
+  for (int i = wave; i < S; i += nwave)
+    for (int j = lane; j < S; j += 64) {
+      const double k = se_k(st[i], st[j], l2, sf2);
+      Kc[(size_t)i * S + j] = k;
+      A[(size_t)i * S + j] = k + (i == j ? sz2 : 0.0);
+    }
   __syncthreads();
   if (!block_cholesky(A, S, S, chol, &sflag)) {
     if (threadIdx.x == 0) *w.status = -6;
     return;
   }
-  // L^-1 column group by column group (4 columns per wave, unit right-hand sides in LDS), stored to B
+  // L^-1, 16 columns at a time (the panel buffer of the factorisation is free: S + 16 <= 384 rows of 17)
   {
-    double (*Xg)[17] = chol.P;  // the panel buffer is free after the factorisation (S <= 160 rows of 17)
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int j0 = 0; j0 < S; j0 += 16) {
-      for (int q = threadIdx.x; q < S * 16; q += blockDim.x) {
-        const int i = q / 16, c = q % 16;
-        Xg[i][c] = (i == j0 + c) ? 1.0 : 0.0;
+    double* Xc = &chol.P[0][0];
+    const int nblk = (S + 15) / 16;
+    for (int jb = 0; jb < nblk; ++jb) {
+      const int rows = (nblk - jb) * 16;
+      for (int q = threadIdx.x; q < rows * 16; q += blockDim.x) Xc[(size_t)(q >> 4) * 17 + (q & 15)] = (q >> 4) == (q & 15) ? 1.0 : 0.0;
+      blocked_lower_solve16(A, S, jb, Xc, sh);
+      for (int i = wave; i < S; i += nwave) {  // column block jb of L^-1: zeros above the diagonal block
+        if (lane < 16 && jb * 16 + lane < S) B[(size_t)i * S + jb * 16 + lane] = i >= jb * 16 ? Xc[(size_t)(i - jb * 16) * 17 + lane] : 0.0;
       }
       __syncthreads();
-      if (j0 + wv * 4 < S) wave_forward<4>(A, S, S, &Xg[0][wv * 4], 17, j0 + wv * 4);
-      __syncthreads();
-      for (int q = threadIdx.x; q < S * 16; q += blockDim.x) {
-        const int i = q / 16, c = q % 16;
-        if (j0 + c < S) B[(size_t)i * S + j0 + c] = Xg[i][c];
-      }
-      __syncthreads();
-      (void)lane;
     }
   }
-  // K^-1 = L^-T L^-1 (symmetric): K^-1[i][j] = sum_{k >= max(i,j)} Li[k][i] Li[k][j]
-  for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
-    const int i = q / S, j = q % S;
-    double s = 0.0;
-    for (int k = (i > j ? i : j); k < S; ++k) s += B[(size_t)k * S + i] * B[(size_t)k * S + j];
-    A[q] = s;
-  }
+  __threadfence_block();
   __syncthreads();
-  double* Kc = w.JtJ + (size_t)c * S * S;   // scratch: the Gram matrix itself (JtJ / lhs are idle until the LM stage, 9 S^2 each)
-  for (int q = threadIdx.x; q < S * S; q += blockDim.x) Kc[q] = se_k(st[q / S], st[q % S], l2, sf2);
+  small_gemm_tn_sym(B, A, S);  // K^-1 = L^-T L^-1
   __syncthreads();
-  for (int q = threadIdx.x; q < S * S; q += blockDim.x) {  // K K^-1, preint.h:838
-    const int i = q / S, j = q % S;
-    double s = 0.0;
-    for (int k = 0; k < S; ++k) s += Kc[(size_t)i * S + k] * A[(size_t)k * S + j];
-    B[q] = s;
-  }
+  small_gemm_nn(Kc, A, B, S);  // K K^-1, preint.h:838
   __syncthreads();
-  for (int j = threadIdx.x; j < S; j += blockDim.x) {  // preint.h:846-864
+  for (int j = wave; j < S; j += nwave) {  // preint.h:846-864: diag(K K^-1 K) by rows (K is symmetric)
     double s = 0.0;
-    for (int k = 0; k < S; ++k) s += B[(size_t)j * S + k] * Kc[(size_t)k * S + j];
-    double v = -s + sf2 + sz2;
-    if (v <= 0) v = sz2;
-    w.var[c * S + j] = v;
-    w.sstd[c * S + j] = sqrt(v);
-    double wt = sqrt(1.0 / (1000.0 * v));  // cost_functions.h:31 with the 1000 x variance of preint.h:853, 864
-    if (isnan(wt)) wt = 1.0;
-    w.wgp[c * S + j] = wt;
+    for (int k = lane; k < S; k += 64) s += B[(size_t)j * S + k] * Kc[(size_t)j * S + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+      double v = -s + sf2 + sz2;
+      if (v <= 0) v = sz2;
+      w.var[c * S + j] = v;
+      w.sstd[c * S + j] = sqrt(v);
+      double wt = sqrt(1.0 / (1000.0 * v));  // cost_functions.h:31 with the 1000 x variance of preint.h:853, 864
+      if (isnan(wt)) wt = 1.0;
+      w.wgp[c * S + j] = wt;
+    }
   }
   if (c < 3) {  // K_int K^-1, preint.h:842-844
-    double* C = w.KintKinv + (size_t)c * S * S;
+    double* Cq = w.KintKinv + (size_t)c * S * S;
     double* Ki = w.lhs + (size_t)c * S * S;  // scratch: K_int
-    for (int q = threadIdx.x; q < S * S; q += blockDim.x) Ki[q] = se_kint(w.start_t, st[q / S], st[q % S], l2, sf2);
+    for (int i = wave; i < S; i += nwave)
+      for (int j = lane; j < S; j += 64) Ki[(size_t)i * S + j] = se_kint(w.start_t, st[i], st[j], l2, sf2);
     __syncthreads();
-    for (int q = threadIdx.x; q < S * S; q += blockDim.x) {
-      const int i = q / S, j = q % S;
-      double s = 0.0;
-      for (int k = 0; k < S; ++k) s += Ki[(size_t)i * S + k] * A[(size_t)k * S + j];
-      C[q] = s;
-    }
+    small_gemm_nn(Ki, A, Cq, S);
   }
 }
 
@@ -1808,79 +1927,6 @@ __global__ __launch_bounds__(512) void corr_factor_kernel(const UgpmWin* __restr
   if (!block_cholesky(w.Ac, n, n, chol, &sflag)) {
     if (threadIdx.x == 0) *w.status = -6;
     return;
-  }
-}
-
-// Blocked forward substitution L X = B for 16 right-hand-side columns by one workgroup of 256 threads, block rows jb .. nblk-1
-// (B is zero above block row jb).  For block row i the update B_i - sum_k L_ik X_k runs on the fp64 matrix cores (the k range is
-// dealt to the 4 waves; operands: L straight from L2 -- the next block row is requested while the triangular solve of the current
-// one runs -- and the X_k tiles from LDS), the 4 partial tiles are added in LDS in wave order, and one wave solves the 16 x 16
-// triangular system for all 16 columns at once (lane = column, L_ii entries broadcast from LDS).
-// X_k lands in Xc + (k - jb) * 16 * 17 as [r][c] at r * 17 + c; rows past n are zero.  On entry Xc holds B in the same layout
-// (the caller fills it with all lanes; a barrier is taken here before it is read).
-struct Solve16Lds {
-  double Pt[4][16][17];  // partial update tiles of the 4 waves
-  double Dl[16][17];     // L_ii
-};
-__device__ __forceinline__ void blocked_lower_solve16(const double* __restrict__ Lm, int n, int jb, double* __restrict__ Xc, Solve16Lds& sh) {
-  const int nblk = (n + 15) / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 15, lk = lane >> 4;
-  // operand prefetch: for block row i, wave v owns k = jb + v, jb + v + 4, ...; element (row i*16 + lr, col k*16 + k0 + lk), k0 = 0,4,8,12
-  constexpr int KMAX = 16;  // blocks per wave per row: supports nblk - jb <= 64 (n <= 1024)
-  double la[KMAX][4];       // one buffer: the next block row is requested right after the matrix cores consumed the current one
-  auto fetch = [&](int i) {
-#pragma unroll
-    for (int t = 0; t < KMAX; ++t) {
-      const int k = jb + wave + 4 * t;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = i * 16 + lr, col = k * 16 + q * 4 + lk;
-        la[t][q] = (k < i && row < n) ? Lm[(size_t)row * n + col] : 0.0;
-      }
-    }
-  };
-  for (int i = jb; i < nblk; ++i) {
-    const int nb = min(16, n - i * 16);
-    {  // diagonal block of L to LDS (lower part; rows past n padded with the identity)
-      const int r = tid >> 4, c = tid & 15;
-      const int row = i * 16 + r, col = i * 16 + c;
-      sh.Dl[r][c] = (c <= r && row < n) ? Lm[(size_t)row * n + col] : ((r == c) ? 1.0 : 0.0);
-    }
-    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
-    if (i > jb) {
-#pragma unroll
-      for (int t = 0; t < KMAX; ++t) {
-        const int k = jb + wave + 4 * t;
-        if (k < i) {
-          const double* xk = Xc + (size_t)(k - jb) * 16 * 17;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[t][q], xk[(q * 4 + lk) * 17 + lr], acc, 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) sh.Pt[wave][lk + 4 * rg][lr] = acc[rg];
-    if (i + 1 < nblk) fetch(i + 1);  // lands while the triangular solve below runs
-    __syncthreads();
-    if (wave == 0 && lane < 16) {  // B_i - sum of partials (wave order), then L_ii X_i = ., column `lane`
-      const int c = lane;
-      double x[16];
-      double* xi = Xc + (size_t)(i - jb) * 16 * 17;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const double bsum = ((sh.Pt[0][r][c] + sh.Pt[1][r][c]) + sh.Pt[2][r][c]) + sh.Pt[3][r][c];
-        double v = xi[r * 17 + c] - bsum;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          if (q < r) v = __builtin_fma(-sh.Dl[r][q], x[q], v);
-        v = v / sh.Dl[r][r];
-        x[r] = (r < nb) ? v : 0.0;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xi[r * 17 + c] = x[r];
-    }
-    __syncthreads();
   }
 }
 
