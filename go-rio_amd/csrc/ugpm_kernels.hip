@@ -1287,6 +1287,15 @@ __device__ __forceinline__ double row_dot(const double* __restrict__ row, const 
   return t;
 }
 
+// row . v for a table row of S doubles, by one wave (lanes along the row: coalesced), result in every lane
+__device__ __forceinline__ double wave_row_dot(const double* __restrict__ row, const double* __restrict__ v, int S) {
+  double t = 0.0;
+  for (int j = threadIdx.x & 63; j < S; j += 64) t += row[j] * v[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  return t;
+}
+
 // Acceptance test of a trust-region step (Ceres 2.1 TrustRegionMinimizer: tolerances of preint.h:943-948, rho > 1e-3, radius
 // update), evaluated from the candidate residuals res_new.  It is fused into the kernels that re-linearise after the step, whose
 // grid has several workgroups per window: EVERY workgroup evaluates the (deterministic) decision for itself from inputs none of
@@ -1377,34 +1386,59 @@ __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict
   }
   __syncthreads();
   for (int c = 0; c < 3; ++c) gpnorm_rows(w, c, x + (size_t)c * S, res + (size_t)c * S, J + (size_t)c * S * n, n, c * S, mode == 2);
-  for (int i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {  // cost_functions.h:201-253
-    double rot[3], drv[3];
-    for (int c = 0; c < 3; ++c) {
-      drv[c] = row_dot(w.KsKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
-      rot[c] = row_dot(w.KsIntKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
+  // cost_functions.h:201-253.  The six table-row dot products of a sample are taken by a whole wave (coalesced rows) into LDS,
+  // then one lane per sample does the SO(3) part.
+  __shared__ double sdot[256][6];
+  for (int ib = i_lo; ib < i_hi; ib += 256) {
+    const int cnt = min(256, i_hi - ib);
+    for (int q = (int)(threadIdx.x >> 6); q < cnt; q += (int)(blockDim.x >> 6)) {
+      const int i = ib + q;
+      for (int c = 0; c < 3; ++c) {
+        const double d0 = wave_row_dot(w.KsKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
+        const double d1 = wave_row_dot(w.KsIntKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
+        if ((threadIdx.x & 63) == 0) {
+          sdot[q][c] = d0;
+          sdot[q][3 + c] = d1;
+        }
+      }
     }
-    const double dtm = w.gyr_t[i] - w.start_t;
-    const V3 rv = v3(rot[0] + dtm * w.hyper[3], rot[1] + dtm * w.hyper[7], rot[2] + dtm * w.hyper[11]);
-    const V3 dv = v3(drv[0] + w.hyper[3], drv[1] + w.hyper[7], drv[2] + w.hyper[11]);
-    const V3 t = mvec(Jr(rv), dv);
-    double* r = res + 3 * S + 3 * i;
-    r[0] = t.x - (w.gyr[i] - w.gyr_bias[0]);  // un-weighted on purpose (cost_functions.h:250)
-    r[1] = t.y - (w.gyr[G + i] - w.gyr_bias[1]);
-    r[2] = t.z - (w.gyr[2 * G + i] - w.gyr_bias[2]);
-    if (mode != 0) {
-      double D[3][6];
-      jacobian_res(rv, dv, D);
-      double* st = w.sample_tmp + (size_t)i * 24;
-      for (int a = 0; a < 3; ++a)
-        for (int k = 0; k < 6; ++k) st[a * 6 + k] = D[a][k];
+    __syncthreads();
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+      const int i = ib + q;
+      const double drv[3] = {sdot[q][0], sdot[q][1], sdot[q][2]}, rot[3] = {sdot[q][3], sdot[q][4], sdot[q][5]};
+      const double dtm = w.gyr_t[i] - w.start_t;
+      const V3 rv = v3(rot[0] + dtm * w.hyper[3], rot[1] + dtm * w.hyper[7], rot[2] + dtm * w.hyper[11]);
+      const V3 dv = v3(drv[0] + w.hyper[3], drv[1] + w.hyper[7], drv[2] + w.hyper[11]);
+      const V3 t = mvec(Jr(rv), dv);
+      double* r = res + 3 * S + 3 * i;
+      r[0] = t.x - (w.gyr[i] - w.gyr_bias[0]);  // un-weighted on purpose (cost_functions.h:250)
+      r[1] = t.y - (w.gyr[G + i] - w.gyr_bias[1]);
+      r[2] = t.z - (w.gyr[2 * G + i] - w.gyr_bias[2]);
+      if (mode != 0) {
+        double D[3][6];
+        jacobian_res(rv, dv, D);
+        double* st = w.sample_tmp + (size_t)i * 24;
+        for (int a = 0; a < 3; ++a)
+          for (int k = 0; k < 6; ++k) st[a * 6 + k] = D[a][k];
+      }
     }
+    __syncthreads();
   }
   if (mode == 0) return;
   __syncthreads();
-  for (size_t q = threadIdx.x; q < (size_t)(i_hi - i_lo) * 3 * n; q += blockDim.x) {  // cost_functions.h:229-246
-    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / n) % 3), i = i_lo + (int)(q / ((size_t)3 * n));
-    const double* st = w.sample_tmp + (size_t)i * 24;
-    J[((size_t)(3 * S + 3 * i + a)) * n + c * S + j] = st[a * 6 + c] * w.KsIntKinv[((size_t)c * G + i) * S + j] + st[a * 6 + c + 3] * w.KsKinv[((size_t)c * G + i) * S + j];
+  {  // cost_functions.h:229-246: one wave per (sample, axis) row, lanes along the S columns of a channel (coalesced, no index division)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (int)(blockDim.x >> 6);
+    for (int rr = wave; rr < (i_hi - i_lo) * 3; rr += nwave) {
+      const int i = i_lo + rr / 3, a = rr % 3;
+      const double* st = w.sample_tmp + (size_t)i * 24;
+      double* row = J + (size_t)(3 * S + 3 * i + a) * n;
+      for (int c = 0; c < 3; ++c) {
+        const double f0 = st[a * 6 + c], f1 = st[a * 6 + c + 3];
+        const double* k0 = w.KsIntKinv + ((size_t)c * G + i) * S;
+        const double* k1 = w.KsKinv + ((size_t)c * G + i) * S;
+        for (int j = lane; j < S; j += 64) row[c * S + j] = f0 * k0[j] + f1 * k1[j];
+      }
+    }
   }
 }
 
@@ -1436,24 +1470,50 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
   __syncthreads();
   for (int c = 0; c < 3; ++c) gpnorm_rows(w, 3 + c, x + (size_t)c * S, res + 3 * V + (size_t)c * S, J + ((size_t)3 * V + (size_t)c * S) * n, n, c * S, mode == 2);
   const double wgt = sqrt(1.0 / w.vel_var);
-  for (int i = i_lo + threadIdx.x; i < i_hi; i += blockDim.x) {  // cost_functions.h:323-381
-    const V3 rv = vel_rot_vec(w, i);
-    const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
-    double vel[3];
-    for (int c = 0; c < 3; ++c) vel[c] = row_dot(w.KvelKinv + ((size_t)c * V + i) * S, x + (size_t)c * S, S);
-    const V3 vv = v3(vel[0] + w.hyper[15], vel[1] + w.hyper[19], vel[2] + w.hyper[23]);
-    const V3 t = mvec(RT, vv);
-    double* r = res + 3 * i;
-    r[0] = (t.x - (w.vel[i] - w.vel_bias[0])) * wgt;
-    r[1] = (t.y - (w.vel[V + i] - w.vel_bias[1])) * wgt;
-    r[2] = (t.z - (w.vel[2 * V + i] - w.vel_bias[2])) * wgt;
-    if (mode != 0) storeM(w.sample_tmp + (size_t)i * 24, RT);
+  // cost_functions.h:323-381; dot products by whole waves as in rot_eval_kernel
+  __shared__ double sdot[256][6];
+  for (int ib = i_lo; ib < i_hi; ib += 256) {
+    const int cnt = min(256, i_hi - ib);
+    for (int q = (int)(threadIdx.x >> 6); q < cnt; q += (int)(blockDim.x >> 6)) {
+      const int i = ib + q;
+      for (int c = 0; c < 3; ++c) {
+        const double d0 = wave_row_dot(w.KgyrIntKinv + ((size_t)c * V + i) * S, w.s_dr + (size_t)c * S, S);  // vel_rot_vec
+        const double d1 = wave_row_dot(w.KvelKinv + ((size_t)c * V + i) * S, x + (size_t)c * S, S);
+        if ((threadIdx.x & 63) == 0) {
+          sdot[q][c] = d0;
+          sdot[q][3 + c] = d1;
+        }
+      }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+      const int i = ib + q;
+      const double dtm = w.vel_t[i] - w.start_t;
+      const V3 rv = v3(sdot[q][0] + dtm * w.hyper[3], sdot[q][1] + dtm * w.hyper[7], sdot[q][2] + dtm * w.hyper[11]);
+      const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
+      const V3 vv = v3(sdot[q][3] + w.hyper[15], sdot[q][4] + w.hyper[19], sdot[q][5] + w.hyper[23]);
+      const V3 t = mvec(RT, vv);
+      double* r = res + 3 * i;
+      r[0] = (t.x - (w.vel[i] - w.vel_bias[0])) * wgt;
+      r[1] = (t.y - (w.vel[V + i] - w.vel_bias[1])) * wgt;
+      r[2] = (t.z - (w.vel[2 * V + i] - w.vel_bias[2])) * wgt;
+      if (mode != 0) storeM(w.sample_tmp + (size_t)i * 24, RT);
+    }
+    __syncthreads();
   }
   if (mode == 0) return;
   __syncthreads();
-  for (size_t q = threadIdx.x; q < (size_t)(i_hi - i_lo) * 3 * n; q += blockDim.x) {  // cost_functions.h:372-376
-    const int j = (int)(q % S), c = (int)((q / S) % 3), a = (int)((q / n) % 3), i = i_lo + (int)(q / ((size_t)3 * n));
-    J[((size_t)(3 * i + a)) * n + c * S + j] = wgt * w.sample_tmp[(size_t)i * 24 + a * 3 + c] * w.KvelKinv[((size_t)c * V + i) * S + j];
+  {  // cost_functions.h:372-376, one wave per (sample, axis) row
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (int)(blockDim.x >> 6);
+    for (int rr = wave; rr < (i_hi - i_lo) * 3; rr += nwave) {
+      const int i = i_lo + rr / 3, a = rr % 3;
+      double* row = J + (size_t)(3 * i + a) * n;
+      for (int c = 0; c < 3; ++c) {
+        const double f = wgt * w.sample_tmp[(size_t)i * 24 + a * 3 + c];
+        const double* k0 = w.KvelKinv + ((size_t)c * V + i) * S;
+        for (int j = lane; j < S; j += 64) row[c * S + j] = f * k0[j];
+      }
+    }
   }
 }
 
