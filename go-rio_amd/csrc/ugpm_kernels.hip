@@ -1287,13 +1287,32 @@ __device__ __forceinline__ double row_dot(const double* __restrict__ row, const 
   return t;
 }
 
-// row . v for a table row of S doubles, by one wave (lanes along the row: coalesced), result in every lane
-__device__ __forceinline__ double wave_row_dot(const double* __restrict__ row, const double* __restrict__ v, int S) {
-  double t = 0.0;
-  for (int j = threadIdx.x & 63; j < S; j += 64) t += row[j] * v[j];
+// Six table-row dot products of one sample by one wave (lanes along the rows: coalesced; all twelve loads of an iteration are in
+// flight together), results in every lane.  rows a[c] (c = 0..2) meet va + c S, rows b[c] meet vb + c S.
+__device__ __forceinline__ void wave_row_dots6(const double* __restrict__ a, size_t a_stride, const double* __restrict__ va,
+                                               const double* __restrict__ b, size_t b_stride, const double* __restrict__ vb, int S, double (&out)[6]) {
+  double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int j = threadIdx.x & 63; j < S; j += 64) {
+    double ra[3], rb[3], xa[3], xb[3];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-  return t;
+    for (int c = 0; c < 3; ++c) {
+      ra[c] = a[c * a_stride + j];
+      rb[c] = b[c * b_stride + j];
+      xa[c] = va[(size_t)c * S + j];
+      xb[c] = vb[(size_t)c * S + j];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      t[c] += ra[c] * xa[c];
+      t[3 + c] += rb[c] * xb[c];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) t[q] += __shfl_xor(t[q], off, 64);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) out[q] = t[q];
 }
 
 // Acceptance test of a trust-region step (Ceres 2.1 TrustRegionMinimizer: tolerances of preint.h:943-948, rho > 1e-3, radius
@@ -1393,13 +1412,11 @@ __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict
     const int cnt = min(256, i_hi - ib);
     for (int q = (int)(threadIdx.x >> 6); q < cnt; q += (int)(blockDim.x >> 6)) {
       const int i = ib + q;
-      for (int c = 0; c < 3; ++c) {
-        const double d0 = wave_row_dot(w.KsKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
-        const double d1 = wave_row_dot(w.KsIntKinv + ((size_t)c * G + i) * S, x + (size_t)c * S, S);
-        if ((threadIdx.x & 63) == 0) {
-          sdot[q][c] = d0;
-          sdot[q][3 + c] = d1;
-        }
+      double d[6];
+      wave_row_dots6(w.KsKinv + (size_t)i * S, (size_t)G * S, x, w.KsIntKinv + (size_t)i * S, (size_t)G * S, x, S, d);
+      if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q2 = 0; q2 < 6; ++q2) sdot[q][q2] = d[q2];
       }
     }
     __syncthreads();
@@ -1476,13 +1493,11 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
     const int cnt = min(256, i_hi - ib);
     for (int q = (int)(threadIdx.x >> 6); q < cnt; q += (int)(blockDim.x >> 6)) {
       const int i = ib + q;
-      for (int c = 0; c < 3; ++c) {
-        const double d0 = wave_row_dot(w.KgyrIntKinv + ((size_t)c * V + i) * S, w.s_dr + (size_t)c * S, S);  // vel_rot_vec
-        const double d1 = wave_row_dot(w.KvelKinv + ((size_t)c * V + i) * S, x + (size_t)c * S, S);
-        if ((threadIdx.x & 63) == 0) {
-          sdot[q][c] = d0;
-          sdot[q][3 + c] = d1;
-        }
+      double d[6];  // 0..2 vel_rot_vec, 3..5 velocity
+      wave_row_dots6(w.KgyrIntKinv + (size_t)i * S, (size_t)V * S, w.s_dr, w.KvelKinv + (size_t)i * S, (size_t)V * S, x, S, d);
+      if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q2 = 0; q2 < 6; ++q2) sdot[q][q2] = d[q2];
       }
     }
     __syncthreads();
