@@ -45,7 +45,7 @@ class ApdParams(C.Structure):
 APD_SYMBOLS = [
     "gorio_apd_create", "gorio_apd_destroy", "gorio_apd_last_error", "gorio_apd_default_params", "gorio_apd_set_params",
     "gorio_apd_get_params", "gorio_apd_set_source", "gorio_apd_set_target", "gorio_apd_set_source_device",
-    "gorio_apd_set_target_device", "gorio_apd_clear_source", "gorio_apd_clear_target", "gorio_apd_swap_source_and_target",
+    "gorio_apd_set_target_device", "gorio_apd_set_clouds_device_batch", "gorio_apd_clear_source", "gorio_apd_clear_target", "gorio_apd_swap_source_and_target",
     "gorio_apd_set_source_covariances", "gorio_apd_set_target_covariances", "gorio_apd_get_source_covariances",
     "gorio_apd_get_target_covariances", "gorio_apd_calculate_covariances", "gorio_apd_get_knn_indices", "gorio_apd_align",
     "gorio_apd_align_batch", "gorio_apd_linearize", "gorio_apd_compute_error", "gorio_apd_get_correspondences",
@@ -287,6 +287,45 @@ class ApdGicp:
         c = (C.c_int * 4)()
         _check(self._h, self._lib.gorio_apd_get_stage_times(self._h, s, c))
         return list(s), list(c)
+
+
+class DeviceCloud(C.Structure):
+    """gorio_apd_device_cloud (include/gorio_apd.h)."""
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("label", C.c_void_p), ("n", C.c_int)]
+
+
+class DeviceInputs:
+    """Descriptor arrays for gorio_apd_set_clouds_device_batch, built once for a list of objects whose inputs live in
+    device-resident SoA buffers: sources / targets = lists of ((x, y, z, label) device addresses, n) per object, or None."""
+
+    def __init__(self, objs, sources=None, targets=None):
+        self.objs = list(objs)
+        n = len(self.objs)
+        self.handles = (C.c_void_p * n)(*[o._h for o in self.objs])
+
+        def pack(lst):
+            if lst is None:
+                return None
+            arr = (DeviceCloud * n)()
+            for i, (ptrs, cnt) in enumerate(lst):
+                arr[i].x, arr[i].y, arr[i].z = ptrs[0], ptrs[1], ptrs[2]
+                arr[i].label = ptrs[3] if len(ptrs) > 3 and ptrs[3] else None
+                arr[i].n = int(cnt)
+            return arr
+        self.src, self.tgt = pack(sources), pack(targets)
+        self._ns = None if sources is None else [int(c) for _, c in sources]
+        self._nt = None if targets is None else [int(c) for _, c in targets]
+
+    def apply(self):
+        """setInputSource / setInputTarget of every object from its device buffers: one C call, one copy launch."""
+        lib = load_library()
+        rc = lib.gorio_apd_set_clouds_device_batch(self.handles, len(self.objs), self.src, self.tgt)
+        _check(self.objs[0]._h, rc)
+        for i, o in enumerate(self.objs):
+            if self._ns is not None:
+                o._n_src = self._ns[i]
+            if self._nt is not None:
+                o._n_tgt = self._nt[i]
 
 
 def align_batch(objs, guesses=None):

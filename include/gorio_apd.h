@@ -87,6 +87,18 @@ int gorio_apd_set_target(gorio_apd_t* h, const float* xyz, const float* label, i
 int gorio_apd_set_source_device(gorio_apd_t* h, const float* d_x, const float* d_y, const float* d_z, const float* d_label, int n);
 int gorio_apd_set_target_device(gorio_apd_t* h, const float* d_x, const float* d_y, const float* d_z, const float* d_label, int n);
 
+/* Batched form of the two calls above for `count` handles on one device: ONE copy launch for all clouds.  source / target: arrays
+ * of `count` descriptors, or NULL to leave that side of every handle untouched.  Same semantics as the single calls: the clouds are
+ * copied (device-to-device, on the library's stream) and the covariances of every touched cloud are invalidated. */
+typedef struct {
+  const float* x;
+  const float* y;
+  const float* z;
+  const float* label; /* may be NULL */
+  int n;
+} gorio_apd_device_cloud;
+int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const gorio_apd_device_cloud* source, const gorio_apd_device_cloud* target);
+
 /* clearSource APD:101-105, clearTarget APD:107-112, swapSourceAndTarget APD:89-98 */
 int gorio_apd_clear_source(gorio_apd_t* h);
 int gorio_apd_clear_target(gorio_apd_t* h);

@@ -380,3 +380,53 @@ def test_pruned_16k_and_map(gpu, gorio):
     assert np.array_equal(cb, cp) and (cb >= 0).sum() > 8000
     assert rel(Hp, Hb) < 1e-12
     assert np.array_equal(gb.getKnnIndices(1), gp.getKnnIndices(1))
+
+
+@pytest.mark.gpu
+def test_device_inputs_single_and_batched_match_host_inputs(gpu, gorio):
+    """gorio_apd_set_*_device and gorio_apd_set_clouds_device_batch copy HBM-resident SoA buffers: same poses and correspondences
+    as the host-pointer path (what bench.py feeds the timed loop with)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")  # the runtime the library itself is linked against (torch ships its own copy)
+    bufs = []
+
+    def dev(a):
+        a = np.ascontiguousarray(a, np.float32)
+        ptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(ptr), C.c_size_t(a.nbytes)) == 0
+        assert hip.hipMemcpy(ptr, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) == 0  # hipMemcpyHostToDevice
+        bufs.append(ptr)
+        return ptr.value
+
+    pairs = [gorio.synth.scan_pair(3000, 3300, seed=40 + q) for q in range(3)]
+    kw = dict(corr_dist_threshold=2.0, search=1, max_iterations=12)
+    ref = []
+    for sx, sl, tx, tl, _ in pairs:
+        g = gorio.ApdGicp(**kw)
+        g.setInputTarget(tx, tl)
+        g.setInputSource(sx, sl)
+        g.align()
+        ref.append((g.getFinalTransformation().copy(), g.getCorrespondences()[0].copy()))
+    srcs, tgts = [], []
+    for sx, sl, tx, tl, _ in pairs:
+        srcs.append(([dev(sx[:, 0]), dev(sx[:, 1]), dev(sx[:, 2]), dev(sl)], sx.shape[0]))
+        tgts.append(([dev(tx[:, 0]), dev(tx[:, 1]), dev(tx[:, 2]), dev(tl)], tx.shape[0]))
+    assert hip.hipDeviceSynchronize() == 0
+    # single calls
+    g = gorio.ApdGicp(**kw)
+    g.setInputTargetDevice(*tgts[0][0], tgts[0][1])
+    g.setInputSourceDevice(*srcs[0][0], srcs[0][1])
+    g.align()
+    assert np.array_equal(g.getFinalTransformation(), ref[0][0])
+    assert np.array_equal(g.getCorrespondences()[0], ref[0][1])
+    # batched call, twice (the second time the buffers of every handle already exist)
+    objs = [gorio.ApdGicp(**kw) for _ in pairs]
+    inputs = gorio.DeviceInputs(objs, sources=srcs, targets=tgts)
+    for _ in range(2):
+        inputs.apply()
+        gorio.align_batch(objs)
+        for o, (T, corr) in zip(objs, ref):
+            assert np.array_equal(o.getFinalTransformation(), T)
+            assert np.array_equal(o.getCorrespondences()[0], corr)
+    for ptr in bufs:
+        hip.hipFree(ptr)
