@@ -255,11 +255,16 @@ __global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restr
       keys[e] = ((unsigned long long)f2ord(c) << 12) | (unsigned long long)e;
     }
     __syncthreads();
-    for (int k = 2; k <= seg; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
+    // bitonic sort of every segment.  Strides >= 256 need the whole workgroup (barrier per stage); smaller strides stay inside
+    // the 256-key window of one wave, where the in-order LDS pipe of the wave is the only synchronisation needed.
+    for (int lk = 1; (1 << lk) <= seg; ++lk) {
+      const int k = 1 << lk;
+      int lj = lk - 1;  // stride j = 1 << lj; pair t -> lo = (t / j) * 2j + t % j, by shifts
+      for (; lj >= 8; --lj) {
+        const int j = 1 << lj;
         for (int r = 0; r < 2; ++r) {
           const int t = tid + 1024 * r;
-          const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+          const int lo = ((t >> lj) << (lj + 1)) | (t & (j - 1)), hi = lo + j;
           const bool up = (k == seg) || ((lo & k) == 0);
           unsigned long long a = keys[lo], b = keys[hi];
           if ((a > b) == up) {
@@ -269,7 +274,26 @@ __global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restr
         }
         __syncthreads();
       }
+      const int wbase = (tid >> 6) * 256;
+      for (; lj >= 0; --lj) {
+        const int j = 1 << lj;
+        for (int r = 0; r < 2; ++r) {
+          const int t = lane + 64 * r;
+          const int lo = wbase + (((t >> lj) << (lj + 1)) | (t & (j - 1))), hi = lo + j;
+          const bool up = (k == seg) || ((lo & k) == 0);
+          unsigned long long a = keys[lo], b = keys[hi];
+          if ((a > b) == up) {
+            keys[lo] = b;
+            keys[hi] = a;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      if (k >= 256 && 2 * k <= seg) __syncthreads();  // the next merge starts with a workgroup-wide stride
     }
+    __syncthreads();
     float nx[4], ny[4], nz[4];
     int no[4];
     for (int r = 0; r < 4; ++r) {
