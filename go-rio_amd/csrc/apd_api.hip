@@ -60,6 +60,7 @@ struct gorio_apd {
   double* partials = nullptr;
   int pt_cap = 0;
   bool corr_valid = false;
+  bool omega_valid = false;  // omega6 holds the Mahalanobis matrices of the last linearisation (not after a Gauss-Newton align)
   PairState* d_state = nullptr;
   PairDesc* d_desc = nullptr;   // batch descriptor array (owned by the handle that leads a batch)
   int desc_cap = 0;
@@ -488,6 +489,8 @@ void fill_desc(gorio_apd* h, PairDesc& d, PairState* state, long total_src_waves
   d.nn_chunk = chunk;
   d.nn_splits = (h->tgt.n_pad + chunk - 1) / chunk;
   d.cl_points = h->params.cl_weight_points;
+  d.write_omega = 1;
+  d.pad_ = 0;
 }
 
 void init_state(PairState& s, const double* T16) {
@@ -580,6 +583,9 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     for (int i = 0; i < 16; ++i) T[i] = (double)guesses[(size_t)q * 16 + i];  // LSQ:56
     init_state(states[q], T);
     fill_desc(hs[q], descs[q], hs[q]->d_state, total_src_waves);
+    // Gauss-Newton never reads the Mahalanobis matrices back (only LM error trials and the parity hooks do): do not store them
+    descs[q].write_omega = lead->params.optimizer == GORIO_OPT_LEVENBERG_MARQUARDT ? 1 : 0;
+    hs[q]->omega_valid = descs[q].write_omega != 0;
     if (descs[q].nn_splits > max_splits) max_splits = descs[q].nn_splits;
     hs[q]->corr_valid = true;
   }
@@ -910,6 +916,7 @@ int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b
   HIP_TRY(h, hipMemcpyAsync(&s, h->d_state, sizeof(s), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->corr_valid = true;
+  h->omega_valid = true;
   if (H && b) {
     std::memcpy(H, s.H, sizeof(double) * 36);
     std::memcpy(b, s.b, sizeof(double) * 6);
@@ -921,7 +928,7 @@ int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b
 int gorio_apd_compute_error(gorio_apd_t* h, const double T[16], double* error) {
   if (!h || !T || !error) return GORIO_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
-  if (!h->corr_valid) return fail(h, GORIO_ERR_STATE, "compute_error needs the correspondences of a previous linearize / align");
+  if (!h->corr_valid || !h->omega_valid) return fail(h, GORIO_ERR_STATE, "compute_error needs the correspondences and Mahalanobis matrices of a previous linearize (or LM align)");
   int rc = single_desc(h);
   if (rc) return rc;
   double xi[16];
@@ -950,7 +957,7 @@ int gorio_apd_get_correspondences(gorio_apd_t* h, int* corr, float* sq_dist, int
 
 int gorio_apd_get_mahalanobis(gorio_apd_t* h, double* maha, int n) {
   if (!h || !maha) return GORIO_ERR_INVALID;
-  if (!h->corr_valid) return fail(h, GORIO_ERR_STATE, "no Mahalanobis matrices held");
+  if (!h->corr_valid || !h->omega_valid) return fail(h, GORIO_ERR_STATE, "no Mahalanobis matrices held (a Gauss-Newton align does not materialise them: call gorio_apd_linearize)");
   if (n != h->src.n) return fail(h, GORIO_ERR_INVALID, "get_mahalanobis: size mismatch");
   HIP_TRY(h, hipSetDevice(h->device));
   std::vector<double> o6((size_t)n * 6);

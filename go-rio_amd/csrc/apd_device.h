@@ -76,6 +76,9 @@ struct PairDesc {
   int nn_splits;     // target range split count for nn_search_kernel
   int nn_chunk;      // candidates per split (multiple of 16)
   int cl_points;     // N of cl_weight = 1/N (APD:273); 0 = src.n
+  int write_omega;   // store the Mahalanobis matrices (mahalanobis_, APDH:111).  Only compute_error reads them back (LM trials, the
+                     // parity hooks); a Gauss-Newton align never does, so it skips the 48 B per point per linearisation
+  int pad_;
 };
 
 struct KnnJob {

@@ -464,7 +464,9 @@ __global__ __launch_bounds__(256) void linearize_kernel(const PairDesc* __restri
       const double q22 = (cB[5] + r22) + (M20 * R20 + M21 * R21 + M22 * R22);
       PointTerms p;
       inv_sym3(q00, q01, q02, q11, q12, q22, p.o00, p.o01, p.o02, p.o11, p.o12, p.o22);  // APD:217
-      om[0] = p.o00; om[1] = p.o01; om[2] = p.o02; om[3] = p.o11; om[4] = p.o12; om[5] = p.o22;
+      if (pd.write_omega) {
+        om[0] = p.o00; om[1] = p.o01; om[2] = p.o02; om[3] = p.o11; om[4] = p.o12; om[5] = p.o22;
+      }
 
       const double quad = residual_terms(T, ax, ay, az, pd.tgt.x[j], pd.tgt.y[j], pd.tgt.z[j], p);  // APD:255-263
       const double w = 1.0 + pd.src.geo_w[i] + ((pd.tgt.label[j] == pd.src.label[i]) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);  // APD:266-276
@@ -494,7 +496,9 @@ __global__ __launch_bounds__(256) void linearize_kernel(const PairDesc* __restri
       acc[23] = G20 * p.e0 + G21 * p.e1 + G22 * p.e2;
       acc[24] = -oe0; acc[25] = -oe1; acc[26] = -oe2;
     } else {
-      om[0] = 0; om[1] = 0; om[2] = 0; om[3] = 0; om[4] = 0; om[5] = 0;
+      if (pd.write_omega) {
+        om[0] = 0; om[1] = 0; om[2] = 0; om[3] = 0; om[4] = 0; om[5] = 0;
+      }
     }
   }
 

@@ -135,7 +135,9 @@ int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b
 /* compute_error APD:310-346: error at T with the correspondences / Mahalanobis matrices of the last linearize */
 int gorio_apd_compute_error(gorio_apd_t* h, const double T[16], double* error);
 /* parity hooks: correspondences_ / sq_distances_ (APDH:113-114) and mahalanobis_ (APDH:111; n*16 doubles, row/col 3 zero;
- * entries of rejected points are zero) of the last linearize */
+ * entries of rejected points are zero) of the last linearize.  The matrices are materialised by gorio_apd_linearize and by a
+ * Levenberg-Marquardt align (whose error trials read them); a Gauss-Newton align skips the store, after it get_mahalanobis and
+ * compute_error return GORIO_ERR_STATE until the next gorio_apd_linearize. */
 int gorio_apd_get_correspondences(gorio_apd_t* h, int* corr, float* sq_dist, int n);
 int gorio_apd_get_mahalanobis(gorio_apd_t* h, double* maha4x4, int n);
 
