@@ -436,7 +436,9 @@ __global__ __launch_bounds__(256) void linearize_kernel(const PairDesc* __restri
       const float rxy = (float)sqrt((double)rxy2);                        // sqrt(float) overload, correctly rounded
       const double elev = (double)(float)atan2((double)rxy, (double)qz);  // atan2(float,float) overload
       const double azim = (double)(float)atan2((double)qy, (double)qx);
-      const double ce = cos(elev), se = sin(elev), ca = cos(azim), sa = sin(azim);
+      double ce, se, ca, sa;  // one range reduction per angle
+      sincos(elev, &se, &ce);
+      sincos(azim, &sa, &ca);
       // A = Rz(az) Ry(el) diag(s): columns of R scaled
       const double A00 = ca * ce * s_x, A01 = -sa * s_y, A02 = ca * se * s_z;
       const double A10 = sa * ce * s_x, A11 = ca * s_y, A12 = sa * se * s_z;
@@ -659,7 +661,13 @@ __global__ __launch_bounds__(1024) void lm_solve_kernel(const PairDesc* __restri
   // deterministic reduction of the block partials (APD:297-304)
   if (threadIdx.x < 28) {
     double s = 0.0;
-    for (int bk = 0; bk < pd.nblk; ++bk) s += pd.partials[(size_t)bk * 28 + threadIdx.x];
+    for (int bk0 = 0; bk0 < pd.nblk; bk0 += 16) {  // same ascending order as a plain loop, but sixteen loads in flight at a time
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (bk0 + u < pd.nblk) ? pd.partials[(size_t)(bk0 + u) * 28 + threadIdx.x] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
     const int t = threadIdx.x;
     if (t < 21) {
       int r = 0, c = t;  // unpack upper-triangular index

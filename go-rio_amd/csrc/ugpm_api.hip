@@ -326,7 +326,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     {
       Stage st(c, 1);
       ug::gram_kernel<<<dim3(6, nw), 256, 0, c.stream>>>(c.d_wins);
-      ug::cross_kernel<<<dim3(12, nw, (std::max(max_G, max_V) + 7) / 8), 256, 0, c.stream>>>(c.d_wins);
+      ug::cross_kernel<<<dim3(12, nw, (std::max(max_G, max_V) + ug::kCrossRows - 1) / ug::kCrossRows), 256, 0, c.stream>>>(c.d_wins);
     }
     {
       Stage st(c, 2);  // state correlation at the LPM-initialised state (a side thread in the reference, preint.h:939)

@@ -1214,8 +1214,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ w
   }
 }
 
-// grid: (12 tables, windows, row tiles of 8), block 256.  Tables 0-2 K_s K^-1 (gyro stamps), 3-5 K_s_int K^-1 (gyro stamps),
+// grid: (12 tables, windows, row tiles of kCrossRows), block 256.  Tables 0-2 K_s K^-1 (gyro stamps), 3-5 K_s_int K^-1 (gyro stamps),
 // 6-8 K_s_int K^-1 (velocity stamps, rotation channels), 9-11 K_s K^-1 (velocity stamps, velocity channels).
+constexpr int kCrossRows = 32;  // table rows per workgroup (8 made 25 k tiny workgroups per batch: dispatch bound)
 __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0) return;
@@ -1228,16 +1229,16 @@ __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ 
   const double* Ki = w.Kinv + (size_t)ch * S * S;
   const double l2 = w.hyper[ch * 4 + 0], sf2 = w.hyper[ch * 4 + 1];
   const bool integral = (kind == 1 || kind == 2);
-  __shared__ double ks[8][160];
-  const int row0 = blockIdx.z * 8;
+  __shared__ double ks[kCrossRows][160];
+  const int row0 = blockIdx.z * kCrossRows;
   if (row0 >= N) return;
-  for (int q = threadIdx.x; q < 8 * S; q += blockDim.x) {
+  for (int q = threadIdx.x; q < kCrossRows * S; q += blockDim.x) {
     const int r = q / S, k = q % S;
     const int n = row0 + r;
     if (n < N) ks[r][k] = integral ? se_kint(w.start_t, tt[n], w.state_t[k], l2, sf2) : se_k(tt[n], w.state_t[k], l2, sf2);
   }
   __syncthreads();
-  for (int q = threadIdx.x; q < 8 * S; q += blockDim.x) {
+  for (int q = threadIdx.x; q < kCrossRows * S; q += blockDim.x) {
     const int r = q / S, j = q % S;
     const int n = row0 + r;
     if (n >= N) continue;
@@ -1545,19 +1546,34 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
   const int part = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* J = w.Jc;
   const double wgt = sqrt(1.0 / w.vel_var);
-  // ---- gyro samples i = part, part + kCorrJacParts, ...
-  for (int i = part + kCorrJacParts * (int)threadIdx.x; i < G; i += kCorrJacParts * (int)blockDim.x) {
-    double rot[3], drv[3];
-    for (int c = 0; c < 3; ++c) {
-      drv[c] = row_dot(w.KsKinv + ((size_t)c * G + i) * S, w.s_dr + (size_t)c * S, S);
-      rot[c] = row_dot(w.KsIntKinv + ((size_t)c * G + i) * S, w.s_dr + (size_t)c * S, S);
+  // ---- gyro samples i = part, part + kCorrJacParts, ...: table dot products by whole waves (wave_row_dots6), then one lane per sample
+  __shared__ double sdot[256][6];
+  {
+    const int nmine = (G - part + kCorrJacParts - 1) / kCorrJacParts;
+    for (int qb = 0; qb < nmine; qb += 256) {
+      const int cnt = min(256, nmine - qb);
+      for (int q = wave; q < cnt; q += 4) {
+        const int i = part + kCorrJacParts * (qb + q);
+        double d[6];
+        wave_row_dots6(w.KsKinv + (size_t)i * S, (size_t)G * S, w.s_dr, w.KsIntKinv + (size_t)i * S, (size_t)G * S, w.s_dr, S, d);
+        if (lane == 0) {
+#pragma unroll
+          for (int q2 = 0; q2 < 6; ++q2) sdot[q][q2] = d[q2];
+        }
+      }
+      __syncthreads();
+      for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+        const int i = part + kCorrJacParts * (qb + q);
+        const double dtm = w.gyr_t[i] - w.start_t;
+        double D[3][6];
+        jacobian_res(v3(sdot[q][3] + dtm * w.hyper[3], sdot[q][4] + dtm * w.hyper[7], sdot[q][5] + dtm * w.hyper[11]),
+                     v3(sdot[q][0] + w.hyper[3], sdot[q][1] + w.hyper[7], sdot[q][2] + w.hyper[11]), D);
+        double* st = w.sample_tmp + (size_t)i * 24;
+        for (int a = 0; a < 3; ++a)
+          for (int k = 0; k < 6; ++k) st[a * 6 + k] = D[a][k];
+      }
+      __syncthreads();
     }
-    const double dtm = w.gyr_t[i] - w.start_t;
-    double D[3][6];
-    jacobian_res(v3(rot[0] + dtm * w.hyper[3], rot[1] + dtm * w.hyper[7], rot[2] + dtm * w.hyper[11]), v3(drv[0] + w.hyper[3], drv[1] + w.hyper[7], drv[2] + w.hyper[11]), D);
-    double* st = w.sample_tmp + (size_t)i * 24;
-    for (int a = 0; a < 3; ++a)
-      for (int k = 0; k < 6; ++k) st[a * 6 + k] = D[a][k];
   }
   __syncthreads();
   {
@@ -1579,16 +1595,33 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
   // ---- velocity samples (cost_functions.h:350-377 with all six blocks); sample_tmp is reused per sample index, and the gyro rows
   // of THIS workgroup that read it are complete (barrier above); other workgroups touch other sample indices only when
   // G and V samples with the same index belong to the same part, which they do (same i -> same part)
-  for (int i = part + kCorrJacParts * (int)threadIdx.x; i < V; i += kCorrJacParts * (int)blockDim.x) {
-    const V3 rv = vel_rot_vec(w, i);
-    const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
-    double vel[3];
-    for (int c = 0; c < 3; ++c) vel[c] = row_dot(w.KvelKinv + ((size_t)c * V + i) * S, w.s_vel + (size_t)c * S, S);
-    const V3 t = mvec(RT, v3(vel[0] + w.hyper[15], vel[1] + w.hyper[19], vel[2] + w.hyper[23]));
-    const M3 dres = mmul(skew(t), Jr(rv));
-    double* st = w.sample_tmp + (size_t)i * 24;
-    storeM(st, dres);
-    storeM(st + 9, RT);
+  {
+    const int nmine = (V - part + kCorrJacParts - 1) / kCorrJacParts;
+    for (int qb = 0; qb < nmine; qb += 256) {
+      const int cnt = min(256, nmine - qb);
+      for (int q = wave; q < cnt; q += 4) {
+        const int i = part + kCorrJacParts * (qb + q);
+        double d[6];  // 0..2 vel_rot_vec, 3..5 velocity
+        wave_row_dots6(w.KgyrIntKinv + (size_t)i * S, (size_t)V * S, w.s_dr, w.KvelKinv + (size_t)i * S, (size_t)V * S, w.s_vel, S, d);
+        if (lane == 0) {
+#pragma unroll
+          for (int q2 = 0; q2 < 6; ++q2) sdot[q][q2] = d[q2];
+        }
+      }
+      __syncthreads();
+      for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+        const int i = part + kCorrJacParts * (qb + q);
+        const double dtm = w.vel_t[i] - w.start_t;
+        const V3 rv = v3(sdot[q][0] + dtm * w.hyper[3], sdot[q][1] + dtm * w.hyper[7], sdot[q][2] + dtm * w.hyper[11]);
+        const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
+        const V3 t = mvec(RT, v3(sdot[q][3] + w.hyper[15], sdot[q][4] + w.hyper[19], sdot[q][5] + w.hyper[23]));
+        const M3 dres = mmul(skew(t), Jr(rv));
+        double* st = w.sample_tmp + (size_t)i * 24;
+        storeM(st, dres);
+        storeM(st + 9, RT);
+      }
+      __syncthreads();
+    }
   }
   __syncthreads();
   {
