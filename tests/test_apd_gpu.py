@@ -47,10 +47,11 @@ def test_knn_indices_bit_exact(gpu, gorio, oracle_apd, n):
     assert np.array_equal(idx, idx_o)
 
 
+@pytest.mark.parametrize("search", [0, 1])
 @pytest.mark.parametrize("k", [5, 20, 27, 32])
-def test_knn_other_k(gpu, gorio, oracle_apd, k):
+def test_knn_other_k(gpu, gorio, oracle_apd, k, search):
     xyz, lab = synth.radar_scan(700, seed=7)
-    g = make(gorio, xyz, lab, xyz, lab, k_correspondences=k)
+    g = make(gorio, xyz, lab, xyz, lab, k_correspondences=k, search=search)
     g.calculateCovariances()
     idx_o, _ = oracle_apd.knn_self(xyz, k)
     assert np.array_equal(g.getKnnIndices(1), idx_o)

@@ -54,6 +54,17 @@ def test_batch_of_windows_and_multiple_queries(gpu, gorio, ugpm_oracle):
             _cmp(a, b)
 
 
+def test_long_window_large_state_count(gpu, gorio, ugpm_oracle):
+    """A 2 s window: S = 116 inducing states, 6S = 696 correlation unknowns -- the large-matrix paths (J^T J with 8-row chunks,
+    Cholesky with more than one panel pass, the 16-column solves with ~100 KB of LDS) against the oracle."""
+    win = synth.imu_window(seed=91, duration=2.0)
+    ro, do = ugpm_oracle.preintegrate(win)
+    rg, dg = gorio.ugpm_preint_batch([win], return_diag=True)
+    assert dg[0]["nb_state"] == do["nb_state"] == 116
+    assert dg[0]["iters_rot"] == do["iters_rot"] and dg[0]["iters_vel"] == do["iters_vel"]
+    _cmp(rg[0][0], ro[0])
+
+
 def test_bias_prior_cov_inflation_and_uncorrelated(gpu, gorio, ugpm_oracle):
     win = synth.imu_window(seed=7)
     kw = dict(gyr_bias=[0.01, -0.02, 0.005], vel_bias=[0.05, 0.0, -0.01], vel_bias_std=0.3, gyr_bias_std=0.03)
