@@ -460,6 +460,56 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   int g0 = (int)(((long)(blockIdx.x * 256 + (threadIdx.x & ~63)) * ng) / (si.n > 0 ? si.n : 1));
   g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);
   const int nsplit = gridDim.y;  // > 1 only when a launch has too few query waves to fill the chip: tile groups are dealt round-robin
+  const bool seeded = st->n_linearize > 0;
+  // Seeded launches (every linearisation of an align but the first) use a WORK LIST: with a tight bound a lane needs ~2 tiles but the
+  // 64 lanes of a wave need ~11 different ones, so evaluating every needed tile for all lanes wastes 4/5 of the distance work.
+  // Instead the tiles some lane needs are staged in LDS (up to kNnSlots per batch -- 8: the kernel is latency bound and 17 KB of LDS
+  // per workgroup keeps five waves per SIMD resident, 16 slots cost 30 % -- one float4 per point: x, y, z, original index)
+  // and each lane walks only ITS OWN tiles, reading candidates from its slot -- lanes of one instruction work on different
+  // tiles.  The tests that select the tiles are the same; a tile is selected against the bound the lane had when the tile was
+  // tested (bounds tighten at every batch), a superset of what the final bound would select, so the result is unchanged.
+  constexpr int kNnSlots = 8;
+  __shared__ float4 s_pts[4][kNnSlots][33];  // 33: slots 528 B apart -> lanes on different slots hit different banks
+  const int wave = threadIdx.x >> 6;
+  const __attribute__((address_space(1))) float* gx = (const __attribute__((address_space(1))) float*)ti.sx;
+  const __attribute__((address_space(1))) float* gy = (const __attribute__((address_space(1))) float*)ti.sy;
+  const __attribute__((address_space(1))) float* gz = (const __attribute__((address_space(1))) float*)ti.sz;
+  const __attribute__((address_space(1))) int* go = (const __attribute__((address_space(1))) int*)ti.orig;
+  unsigned int mneed = 0u;  // slots of the current batch this lane must visit
+  int slot_tile = 0;        // lane s: tile held by slot s
+  int nslots = 0;           // wave-uniform
+  auto flush = [&]() {
+    for (int s0 = 0; s0 < nslots; s0 += 2) {  // two slots per pass: lanes 0-31 / 32-63 bring one point each
+      const int my = s0 + (lane >> 5);
+      const int tile = __shfl(slot_tile, my < nslots ? my : s0, 64);
+      if (my < nslots) {
+        const int j = tile * 32 + (lane & 31);
+        s_pts[wave][my][lane & 31] = make_float4(gx[j], gy[j], gz[j], __int_as_float(go[j]));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    STAT_ADD(3, __builtin_popcount(mneed));  // lane 0's own item count (a sample of the per-lane mean)
+    while (__ballot(mneed != 0u)) {
+      STAT_ADD(4, 1);
+      if (mneed != 0u) {
+        const int sl = __builtin_ctz(mneed);
+        mneed &= mneed - 1u;
+        const float4* __restrict__ cp = s_pts[wave][sl];
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+          const float4 c = cp[k];
+          const float d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+          const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(c.w);
+          best = key < best ? key : best;
+        }
+      }
+    }
+    bestd = __uint_as_float((unsigned int)(best >> 32));
+    nslots = 0;
+    __builtin_amdgcn_wave_barrier();
+  };
   for (int v = 0; v < 2 * ng; ++v) {
     const int off = (v + 1) >> 1;
     const int g = (v & 1) ? g0 - off : g0 + off;
@@ -473,13 +523,20 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
     }
     const float wb = wave_max(bestd);
     unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= wb);
+    STAT_ADD(7, __builtin_popcountll(mask));
     while (mask) {
       const int tlane = __builtin_ctzll(mask);
       mask &= mask - 1;
       const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
-      if (__ballot(box_bound(qx, qy, qz, bx) <= bestd) == 0) continue;
+      const bool need = box_bound(qx, qy, qz, bx) <= bestd;
+      if (__ballot(need) == 0) continue;
       STAT_ADD(6, 1);
-      STAT_ADD(7, __builtin_popcountll(__ballot(box_bound(qx, qy, qz, bx) <= bestd)));
+      if (seeded) {
+        if (need) mneed |= 1u << nslots;
+        if (lane == nslots) slot_tile = g * 64 + tlane;
+        if (++nslots == kNnSlots) flush();
+        continue;
+      }
       const int j0 = (g * 64 + tlane) * 32;
 #pragma unroll
       for (int gg = 0; gg < 32; gg += 8) {
@@ -495,6 +552,7 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
       bestd = __uint_as_float((unsigned int)(best >> 32));
     }
   }
+  if (nslots > 0) flush();
   if (p < si.n && (unsigned int)best != 0xffffffffu) {
     if (nsplit > 1) atomicMin(pd.best_key + si.orig[p], best);
     else pd.best_key[si.orig[p]] = best;

@@ -21,4 +21,4 @@ if have_stats:
     st = (C.c_ulonglong * 8)(); lib.gorio_debug_search_stats(st, 0)
     v = list(st)
     print("knn: waves", v[0], "coarse tiles/wave", v[1] / max(v[0], 1), "evaluated tiles/wave", v[2] / max(v[0], 1), "insert rounds/wave", v[3] / max(v[0], 1), "lanes needing a tile", v[4] / max(v[2], 1))
-    print("nn: waves", v[5], "evaluated tiles/wave", v[6] / max(v[5], 1), "lanes needing a tile", v[7] / max(v[6], 1))
+    print("nn: waves", v[5], "needed (union) tiles/wave", v[6] / max(v[5], 1), "coarse-passed tiles/wave", v[7] / max(v[5], 1), "work-list rounds/wave", v[4] / max(v[5], 1), "items of lane 0 per wave", v[3] / max(v[5], 1))
