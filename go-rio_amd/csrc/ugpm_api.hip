@@ -321,6 +321,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     };
     {
       Stage st(c, 0);
+      ug::lpm_rot_kernel<<<dim3(nw, 5), 320, 0, c.stream>>>(c.d_wins);
       ug::lpm_init_kernel<<<nw, 320, 0, c.stream>>>(c.d_wins);
     }
     {

@@ -585,27 +585,34 @@ __device__ void unwrap_variant(const UgpmWin& w, int variant) {
 }
 
 // grid: (windows), block 320 = 5 waves; wave v's first lane integrates LPM variant v.
-__global__ __launch_bounds__(320) void lpm_init_kernel(const UgpmWin* __restrict__ wins) {
+// LPM initialisation, part 1: one workgroup per (window, integration).  The five rotation integrations (nominal, time-shifted, three
+// gyro-bias perturbations) are independent, so they run side by side; each is followed by its own 2 pi unwrapping, and the nominal
+// one by the trapezoid position integration that needs its re-projected velocities.  grid: (windows, 5), block 320.
+__global__ __launch_bounds__(320) void lpm_rot_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0) return;
-  const int v = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int S = w.S;
+  const int var = blockIdx.y, lane = threadIdx.x & 63;
   __shared__ LpmLds lds;
   {
-    // scratch for the P(i) sequence: the (still unused) rotation-problem Jacobian buffer
-    double* Rseq = w.Jrot;
-    const size_t cap = (size_t)(3 * w.S + 3 * w.G) * 3 * w.S;
-    bool par_ok = true;
-    for (int var = 0; var < 5 && par_ok; ++var) par_ok = lpm_rotation_parallel(w, var, lds, Rseq, cap);
-    if (!par_ok) {  // time line too long for the LDS form: one lane per integration
-      if (lane == 0) lpm_rotation(w, v);
+    // scratch for the P(i) sequence: a fifth of the (still unused) rotation-problem Jacobian buffer per integration
+    const size_t cap = ((size_t)(3 * w.S + 3 * w.G) * 3 * w.S) / 5;
+    double* Rseq = w.Jrot + (size_t)var * cap;
+    if (!lpm_rotation_parallel(w, var, lds, Rseq, cap)) {  // time line too long for the LDS form: one lane integrates
+      if (threadIdx.x == 0) lpm_rotation(w, var);
     }
   }
   __syncthreads();
-  if (v == 0 && lane < 3) lpm_position(w, lane);
-  if (lane == 0) unwrap_variant(w, v);
-  __syncthreads();
+  if (var == 0 && threadIdx.x < 3) lpm_position(w, threadIdx.x);
+  if (threadIdx.x == 64) unwrap_variant(w, var);
+  (void)lane;
+}
+
+// LPM initialisation, part 2 (after all five integrations): GP state seeds, their finite-difference Jacobians, hyper-parameters.
+// grid: (windows), block 320.
+__global__ __launch_bounds__(320) void lpm_init_kernel(const UgpmWin* __restrict__ wins) {
+  const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0) return;
+  const int S = w.S;
   const M3 sRt0 = mtr(loadM(w.Rstart));
   for (int i = threadIdx.x; i < S; i += blockDim.x) {  // preint.h:1231-1236, 1304-1307, 1369-1372
     const V3 a0 = load3(w.r0 + (size_t)i * 3), a1 = load3(w.r1 + (size_t)i * 3);
