@@ -299,7 +299,8 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   UHIP(hipMemcpyAsync(c.d_wins, dw.data(), sizeof(UgpmWin) * n_windows, hipMemcpyHostToDevice, c.stream));
   UHIP(hipMemcpyAsync(c.d_ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice, c.stream));
   tt1 = tnow();
-  UHIP(hipStreamSynchronize(c.stream));  // staging vectors are pageable
+  // no synchronisation here: the three staging vectors outlive every use of them (they are locals of this call, which ends with a
+  // stream synchronisation), and the kernels below are ordered behind the copies on the same stream
   tt2 = tnow();
 
   const int nw = n_windows;
@@ -353,7 +354,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
         } else {
           ug::lm_relinearize_linear_kernel<<<dim3(nw, (3 * max_S + 63) / 64), 256, 0, c.stream>>>(c.d_wins);  // linear problem: J and J^T J stay exact
         }
-        if ((it & 1) == 1) {  // poll the done flags every other iteration
+        if (it >= 3 && (it & 1) == 1) {  // poll the done flags every other iteration (no window of the C2 shape finishes in fewer than four)
           UHIP(hipMemcpyAsync(flags.data(), c.d_ints, sizeof(int) * flags.size(), hipMemcpyDeviceToHost, c.stream));
           UHIP(hipStreamSynchronize(c.stream));
           bool all = true;
