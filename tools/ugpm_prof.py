@@ -1,4 +1,6 @@
-import importlib, sys, time
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib, time
 import numpy as np
 gorio = importlib.import_module("go-rio_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import importlib, sys, time
 import numpy as np
 if len(sys.argv) > 1 and sys.argv[1] == "torch":
