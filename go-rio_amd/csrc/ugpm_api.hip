@@ -175,9 +175,12 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     // ata_kernel stages J through up to ~128 KB of dynamic LDS (the default limit is 64 KB)
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::corr_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::infer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (6 * 160 + 16) * 8) /* S = 160: with the 31 KB of static LDS this is just inside the 160 KB of a CU */);
-    UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-    UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-    UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::ata_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    {
+      const void* fns[] = {reinterpret_cast<const void*>(&ug::ata_kernel<4, 16, kAtaTilesCorr>), reinterpret_cast<const void*>(&ug::ata_kernel<8, 16, kAtaTilesCorr>),
+                           reinterpret_cast<const void*>(&ug::ata_kernel<16, 8, kAtaTilesCorr>), reinterpret_cast<const void*>(&ug::ata_kernel<4, 32, kAtaTilesLm>),
+                           reinterpret_cast<const void*>(&ug::ata_kernel<8, 16, kAtaTilesLm>)};
+      for (const void* f : fns) UHIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    }
   }
   for (int i = 0; i < 5; ++i) { g_stage_s[i] = 0; g_stage_n[i] = 0; }
   const bool trace = std::getenv("GORIO_UGPM_TRACE") != nullptr;
@@ -310,15 +313,21 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     // J^T J launches: one workgroup per (row slice, tile group, window), see ata_kernel
     auto launch_ata = [&](int which) {
       const int n = (which == 2 ? 6 : 3) * max_S, T = (n + 15) / 16, ntile = T * (T + 1) / 2;
-      const int ng = (ntile + kAtaTilesPerGroup - 1) / kAtaTilesPerGroup;
+      const int tpg = which == 2 ? kAtaTilesCorr : kAtaTilesLm;
+      const int ng = (ntile + tpg - 1) / tpg;
       const int npad = ((n + 15) / 32) * 32 + 16;
       const int units = nw * ng, grid = ((units + 7) / 8) * kAtaKSplit * 8;
       // at least 84 KB of LDS per workgroup: two of them must not share a CU (they would halve each other's matrix-core rate
       // while other CUs idle)
       auto lds = [&](int kc) { return std::max(sizeof(double) * 2 * kc * (npad + 1), (size_t)84 * 1024); };
-      if (npad <= 256) ug::ata_kernel<4, 16><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
-      else if (npad <= 512) ug::ata_kernel<8, 16><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
-      else ug::ata_kernel<16, 8><<<grid, 512, lds(8), c.stream>>>(c.d_wins, which, nw, ng);
+      if (which == 2) {
+        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesCorr><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
+        else if (npad <= 512) ug::ata_kernel<8, 16, kAtaTilesCorr><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
+        else ug::ata_kernel<16, 8, kAtaTilesCorr><<<grid, 512, lds(8), c.stream>>>(c.d_wins, which, nw, ng);
+      } else {
+        if (npad <= 256) ug::ata_kernel<4, 32, kAtaTilesLm><<<grid, 512, lds(32), c.stream>>>(c.d_wins, which, nw, ng);  // 107 KB of LDS: half the barriers
+        else ug::ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);  // n = 3S <= 480
+      }
     };
     {
       Stage st(c, 0);

@@ -1665,8 +1665,9 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
 // which: 0 rot problem, 1 vel problem, 2 correlation.  Dynamic LDS: 2 * KC * (npad + 1) doubles.  n <= 512 when g is formed.
 __device__ __forceinline__ int ata_npad(int n) { return ((n + 15) / 32) * 32 + 16; }  // >= round_up(n, 16); rows 32 banks apart
 
-// CMAX = 64-column groups of a staged row (npad <= 64 CMAX), KC = rows per staged chunk.
-template <int CMAX, int KC>
+// CMAX = 64-column groups of a staged row (npad <= 64 CMAX), KC = rows per staged chunk, TPG = output tiles per workgroup (8 waves x
+// TPG / 8 accumulators): 32 for the LM problems (n = 3S: more, shorter workgroups), 48 for the correlation (n = 6S).
+template <int CMAX, int KC, int TPG>
 __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wins, int which, int n_windows, int groups_max) {
   const int L = blockIdx.x;
   const int xcd = L & 7, pslot = L >> 3;
@@ -1692,7 +1693,7 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
     C = w.JtJ; r = w.res; g = w.lmv;
   }
   const int T = (n + 15) / 16, ntile = T * (T + 1) / 2;
-  const int ng = (ntile + kAtaTilesPerGroup - 1) / kAtaTilesPerGroup;
+  const int ng = (ntile + TPG - 1) / TPG;
   if (grp >= ng) return;
   const int q_lo = (int)((long)grp * ntile / ng), q_hi = (int)((long)(grp + 1) * ntile / ng);
   const int npad = ata_npad(n);
@@ -1703,7 +1704,7 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
-  constexpr int NT = 12;
+  constexpr int NT = TPG / 8;
   // this wave's tiles: q = q_lo + wave + 8 t.  Slots past the end of the group repeat the group's last tile (computed, not stored):
   // the loop below then has no branches and the compiler can keep all operand reads of a k-step in flight ahead of the MFMAs.
   int trofs[NT], tcofs[NT], qv[NT];
@@ -1784,6 +1785,23 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
     CHOL_T(3);
     __syncthreads();
     CHOL_T(4);
+  }
+  if constexpr (kAtaKSplit == 1) {  // this workgroup saw every row: its accumulators ARE the result
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int i = trofs[t] + lk + 4 * rg, j = tcofs[t] + lr;
+          if (i < n && j < n) {
+            C[(size_t)i * n + j] = acc[t][rg];
+            C[(size_t)j * n + i] = acc[t][rg];
+          }
+        }
+      }
+    }
+    if (g != nullptr && grp == 0 && tid < n) g[tid] = gacc;
+    return;
   }
   // partial results, accumulator order: [(ks * ntile + q) * 256 + reg * 64 + lane]
   double* part = w.ata_part;

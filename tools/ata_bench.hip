@@ -12,7 +12,7 @@ using namespace gorio::ug;
 int main(int argc, char** argv) {
   const int S = argc > 1 ? atoi(argv[1]) : 66, G = argc > 2 ? atoi(argv[2]) : 260, nw = argc > 3 ? atoi(argv[3]) : 64, reps = 10;
   const int n = 3 * S, m = 3 * S + 3 * G;
-  const int T = (n + 15) / 16, ntile = T * (T + 1) / 2, ng = (ntile + kAtaTilesPerGroup - 1) / kAtaTilesPerGroup;
+  const int T = (n + 15) / 16, ntile = T * (T + 1) / 2, ng = (ntile + kAtaTilesLm - 1) / kAtaTilesLm;
   std::vector<UgpmWin> hw(nw);
   std::vector<double> J((size_t)m * n), rr(m);
   srand(3);
@@ -45,11 +45,11 @@ int main(int argc, char** argv) {
   const int npad = ((n + 15) / 32) * 32 + 16;
   const int units = nw * ng, grid = ((units + 7) / 8) * kAtaKSplit * 8;
   const size_t lds = sizeof(double) * 2 * 16 * (npad + 1);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&ata_kernel<4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&ata_kernel<8, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&ata_kernel<4, 16, kAtaTilesLm>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&ata_kernel<8, 16, kAtaTilesLm>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
   auto launch = [&] {
-    if (npad <= 256) ata_kernel<4, 16><<<grid, 512, lds>>>(dw, 0, nw, ng);
-    else ata_kernel<8, 16><<<grid, 512, lds>>>(dw, 0, nw, ng);
+    if (npad <= 256) ata_kernel<4, 16, kAtaTilesLm><<<grid, 512, lds>>>(dw, 0, nw, ng);
+    else ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds>>>(dw, 0, nw, ng);
   };
   launch();
   hipDeviceSynchronize();
