@@ -687,8 +687,9 @@ __device__ long long g_chol_t[12];
 #endif
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 struct CholLds {
-  double D[kCholNB][kCholNB + 1];
-  double Dinv[kCholNB];
+  double D[2][kCholNB][kCholNB + 1];   // factored diagonal block (double buffered for the look-ahead)
+  double Dinv[2][kCholNB];
+  double Dt[kCholNB][kCholNB + 1];      // next diagonal block after its trailing update, on its way from MFMA layout to one row per lane
   double dinv_n[384];        // 1 / L[i][i] of every row, kept for block_backward (filled when a right-hand side is carried)
   unsigned short tile[328];  // q -> (tile row << 8 | tile column) of the lower-triangular 16 x 16 tiling, q = tr (tr + 1) / 2 + tc, tr < 25
   double P[kCholMaxN > 384 ? 384 : kCholMaxN][kCholNB + 1];  // panel rows of the current block column (n - kb - NB <= 384 rows handled per pass)
@@ -725,6 +726,43 @@ __device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, in
   }
   __syncthreads();
   CHOL_T_INIT;
+  // LOOK-AHEAD (matrices that fit one panel pass): the serial factorisation of the NEXT diagonal block runs on wave 0 while the
+  // other waves do the trailing update of the current panel -- wave 0 first updates that one 16 x 16 tile, stages it in LDS,
+  // re-reads it one row per lane and factors it in registers.  The diagonal block buffers are double buffered.
+  const bool la = n - min(NB, n) + (rhs != nullptr ? 1 : 0) <= 384 && nwave >= 2;  // the first panel (the longest) fits one pass
+  int cur = 0;
+  // factor the 16 x 16 block held one row per lane in a[] (lane r = row r, identity rows pad a short block), publish it in
+  // L.D[buf] / L.Dinv[buf] and in A
+  auto factor_block = [&](double (&a)[NB], int kbd, int nbd, int buf) {
+    const int r = lane;
+    bool ok = true;
+    double yinv = 1.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const double ajj = readlane_f64(a[j], j);
+      if (!(ajj > 0.0)) ok = false;
+      const double y = rsqrt_newton(ajj);
+      const double lrj = a[j] * y;  // row j: a_jj / sqrt(a_jj) = sqrt(a_jj)
+      if (r == j) yinv = y;
+      a[j] = lrj;
+#pragma unroll
+      for (int c = j + 1; c < NB; ++c) {
+        const double lcj = readlane_f64(lrj, c);
+        a[c] = __builtin_fma(-lrj, lcj, a[c]);  // meaningful for r >= c only; the upper part of a[] is never read
+      }
+    }
+    if (r < NB) {
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+        if (c <= r) {
+          L.D[buf][r][c] = a[c];
+          if (r < nbd) A[(size_t)(kbd + r) * lda + kbd + c] = a[c];
+        }
+      L.Dinv[buf][r] = yinv;
+      if (rhs != nullptr && r < nbd) L.dinv_n[kbd + r] = yinv;
+    }
+    if (!ok && lane == 0) *sflag = 1;
+  };
   for (int kb = 0; kb < n; kb += NB) {
     const int nb = min(NB, n - kb);
     const int m = n - kb - nb;  // rows below the diagonal block
@@ -736,50 +774,23 @@ __device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, in
 #pragma unroll
       for (int c = 0; c < NB; ++c) x[c] = c < nb ? arow[c] : 0.0;
     };
-    // waves that do not factor request their first panel row now: it does not depend on the factor
-    if (wave != 0 && own) load_row(panel_row(tid));
-    if (wave == 0) {  // diagonal block, lane r = row r, in registers.  A short last block is padded with identity rows.
-      const int r = lane;
-      double a[NB];
+    if (!la || kb == 0) {
+      // waves that do not factor request their first panel row now: it does not depend on the factor
+      if (wave != 0 && own) load_row(panel_row(tid));
+      if (wave == 0) {  // diagonal block from memory
+        const int r = lane;
+        double a[NB];
 #pragma unroll
-      for (int c = 0; c < NB; ++c) a[c] = (r < nb && c <= r) ? A[(size_t)(kb + r) * lda + kb + c] : ((r == c) ? 1.0 : 0.0);
-      CHOL_T_VMWAIT;
-      CHOL_T(8);
-      bool ok = true;
-      double yinv = 1.0;
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const double ajj = readlane_f64(a[j], j);
-        if (!(ajj > 0.0)) ok = false;
-        const double y = rsqrt_newton(ajj);
-        const double lrj = a[j] * y;  // row j: a_jj / sqrt(a_jj) = sqrt(a_jj)
-        if (r == j) yinv = y;
-        a[j] = lrj;
-#pragma unroll
-        for (int c = j + 1; c < NB; ++c) {
-          const double lcj = readlane_f64(lrj, c);
-          a[c] = __builtin_fma(-lrj, lcj, a[c]);  // meaningful for r >= c only; the upper part of a[] is never read
-        }
+        for (int c = 0; c < NB; ++c) a[c] = (r < nb && c <= r) ? A[(size_t)(kb + r) * lda + kb + c] : ((r == c) ? 1.0 : 0.0);
+        factor_block(a, kb, nb, cur);
+        if (own) load_row(panel_row(tid));
       }
-      if (r < NB) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-          if (c <= r) {
-            L.D[r][c] = a[c];
-            if (r < nb) A[(size_t)(kb + r) * lda + kb + c] = a[c];
-          }
-        L.Dinv[r] = yinv;
-        if (rhs != nullptr && r < nb) L.dinv_n[kb + r] = yinv;
-      }
-      if (!ok && lane == 0) *sflag = 1;
-      CHOL_T(9);
-      if (own) load_row(panel_row(tid));
-      CHOL_T_VMWAIT;
-      CHOL_T(10);
+      CHOL_T(0);
+      __syncthreads();
+      CHOL_T(1);
+    } else if (own) {
+      load_row(panel_row(tid));  // the block was factored during the previous trailing update (barrier at its end)
     }
-    CHOL_T(0);
-    __syncthreads();
-    CHOL_T(1);
     if (*sflag) return false;
     if (me <= 0) break;
     for (int p0 = 0; p0 < me; p0 += 384) {  // panel passes (one pass unless n > 400)
@@ -793,8 +804,8 @@ __device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, in
         for (int c = 0; c < NB; ++c) {
           double v = x[c];
 #pragma unroll
-          for (int q = 0; q < c; ++q) v = __builtin_fma(-x[q], L.D[c][q], v);
-          v *= L.Dinv[c];
+          for (int q = 0; q < c; ++q) v = __builtin_fma(-x[q], L.D[cur][c][q], v);
+          v *= L.Dinv[cur][c];
           x[c] = v;
           L.P[i][c] = v;
         }
@@ -828,51 +839,74 @@ __device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, in
         const double* Pl = &L.P[0][0] + (lr * (NB + 1) + lk);
         double* Abase = A + (size_t)(kb + nb) * lda + kb + nb;
         constexpr int TU = 4;
-        for (int q0 = wave_u * TU; q0 < ntile; q0 += nwave * TU) {
-          int trv[TU], tcv[TU];
-          double cv[TU][4];
+        const bool ahead = la && m > 0;           // wave 0: tile 0 (the next diagonal block) and its factorisation
+        const int q_first = ahead ? 1 : 0;        // tiles left to the tiling loop
+        const int w_first = ahead ? 1 : 0, w_cnt = nwave - w_first;
+        if (ahead && wave_u == 0) {
+          double val[4];
 #pragma unroll
-          for (int u = 0; u < TU; ++u) {
-            const int t = __builtin_amdgcn_readfirstlane((int)L.tile[min(q0 + u, ntile - 1)]);
-            trv[u] = t >> 8;
-            tcv[u] = t & 255;
-            const double* tb = Abase + (size_t)(trv[u] * 16) * lda + tcv[u] * 16;
-            if (q0 + u < ntile) {
+          for (int rg = 0; rg < 4; ++rg) val[rg] = (lk + 4 * rg < mt && lr < mt) ? Abase[vofs + rg * rstep] : 0.0;
+          f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int k0 = 0; k0 < NB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pl[k0], Pl[k0], acc, 0, 0, 0);
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) L.Dt[lk + 4 * rg][lr] = val[rg] - acc[rg];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int nbn = min(NB, m), r = lane;
+          double a[NB];
+#pragma unroll
+          for (int c = 0; c < NB; ++c) a[c] = (r < nbn && c <= r) ? L.Dt[r][c] : ((r == c) ? 1.0 : 0.0);
+          factor_block(a, kb + nb, nbn, cur ^ 1);
+        }
+        if (wave_u >= w_first) {
+          for (int q0 = q_first + (wave_u - w_first) * TU; q0 < ntile; q0 += w_cnt * TU) {
+            int trv[TU], tcv[TU];
+            double cv[TU][4];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+              const int t = __builtin_amdgcn_readfirstlane((int)L.tile[min(q0 + u, ntile - 1)]);
+              trv[u] = t >> 8;
+              tcv[u] = t & 255;
+              const double* tb = Abase + (size_t)(trv[u] * 16) * lda + tcv[u] * 16;
+              if (q0 + u < ntile) {
+                if (trv[u] * 16 + 16 <= mt) {
+#pragma unroll
+                  for (int rg = 0; rg < 4; ++rg) cv[u][rg] = tb[vofs + rg * rstep];
+                } else {
+#pragma unroll
+                  for (int rg = 0; rg < 4; ++rg)
+                    cv[u][rg] = (trv[u] * 16 + lk + 4 * rg < mt && tcv[u] * 16 + lr < mt) ? tb[vofs + rg * rstep] : 0.0;
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+              if (q0 + u >= ntile) break;
+              const double* pa = Pl + trv[u] * 16 * (NB + 1);
+              const double* pb = Pl + tcv[u] * 16 * (NB + 1);
+              f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int k0 = 0; k0 < NB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+              double* tb = Abase + (size_t)(trv[u] * 16) * lda + tcv[u] * 16;
               if (trv[u] * 16 + 16 <= mt) {
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) cv[u][rg] = tb[vofs + rg * rstep];
+                for (int rg = 0; rg < 4; ++rg) tb[vofs + rg * rstep] = cv[u][rg] - acc[rg];
               } else {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
-                  cv[u][rg] = (trv[u] * 16 + lk + 4 * rg < mt && tcv[u] * 16 + lr < mt) ? tb[vofs + rg * rstep] : 0.0;
+                  if (trv[u] * 16 + lk + 4 * rg < mt && tcv[u] * 16 + lr < mt) tb[vofs + rg * rstep] = cv[u][rg] - acc[rg];
               }
             }
           }
+          if (rhs != nullptr) {  // the right-hand-side row: rhs[k] -= P[m] . P[k]
+            for (int k = tid - w_first * 64; k < m; k += w_cnt * 64) {
+              double acc = 0.0;
 #pragma unroll
-          for (int u = 0; u < TU; ++u) {
-            if (q0 + u >= ntile) break;
-            const double* pa = Pl + trv[u] * 16 * (NB + 1);
-            const double* pb = Pl + tcv[u] * 16 * (NB + 1);
-            f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k0 = 0; k0 < NB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
-            double* tb = Abase + (size_t)(trv[u] * 16) * lda + tcv[u] * 16;
-            if (trv[u] * 16 + 16 <= mt) {
-#pragma unroll
-              for (int rg = 0; rg < 4; ++rg) tb[vofs + rg * rstep] = cv[u][rg] - acc[rg];
-            } else {
-#pragma unroll
-              for (int rg = 0; rg < 4; ++rg)
-                if (trv[u] * 16 + lk + 4 * rg < mt && tcv[u] * 16 + lr < mt) tb[vofs + rg * rstep] = cv[u][rg] - acc[rg];
+              for (int c = 0; c < NB; ++c) acc = __builtin_fma(L.P[m][c], L.P[k][c], acc);
+              rhs[kb + nb + k] -= acc;
             }
-          }
-        }
-        if (rhs != nullptr) {  // the right-hand-side row: rhs[k] -= P[m] . P[k]
-          for (int k = tid; k < m; k += blockDim.x) {
-            double acc = 0.0;
-#pragma unroll
-            for (int c = 0; c < NB; ++c) acc = __builtin_fma(L.P[m][c], L.P[k][c], acc);
-            rhs[kb + nb + k] -= acc;
           }
         }
       }
@@ -889,6 +923,7 @@ __device__ __forceinline__ bool block_cholesky(double* __restrict__ A, int n, in
       __syncthreads();
       CHOL_T(5);
     }
+    if (la) cur ^= 1;
   }
   __syncthreads();
   return true;
