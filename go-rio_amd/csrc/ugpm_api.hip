@@ -177,7 +177,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::infer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (6 * 160 + 16) * 8) /* S = 160: with the 31 KB of static LDS this is just inside the 160 KB of a CU */);
     {
       const void* fns[] = {reinterpret_cast<const void*>(&ug::ata_kernel<4, 16, kAtaTilesCorr>), reinterpret_cast<const void*>(&ug::ata_kernel<8, 16, kAtaTilesCorr>),
-                           reinterpret_cast<const void*>(&ug::ata_kernel<16, 8, kAtaTilesCorr>), reinterpret_cast<const void*>(&ug::ata_kernel<4, 32, kAtaTilesLm>),
+                           reinterpret_cast<const void*>(&ug::ata_kernel<16, 8, kAtaTilesCorr>), reinterpret_cast<const void*>(&ug::ata_kernel<4, 16, kAtaTilesLm>),
                            reinterpret_cast<const void*>(&ug::ata_kernel<8, 16, kAtaTilesLm>)};
       for (const void* f : fns) UHIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     }
@@ -317,15 +317,14 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       const int ng = (ntile + tpg - 1) / tpg;
       const int npad = ((n + 15) / 32) * 32 + 16;
       const int units = nw * ng, grid = ((units + 7) / 8) * kAtaKSplit * 8;
-      // at least 84 KB of LDS per workgroup: two of them must not share a CU (they would halve each other's matrix-core rate
-      // while other CUs idle)
-      auto lds = [&](int kc) { return std::max(sizeof(double) * 2 * kc * (npad + 1), (size_t)84 * 1024); };
+      // LDS as small as the staging needs (53 KB at n = 198): the scan matcher's kernels share the CUs with these workgroups
+      auto lds = [&](int kc) { return sizeof(double) * 2 * kc * (npad + 1); };
       if (which == 2) {
         if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesCorr><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
         else if (npad <= 512) ug::ata_kernel<8, 16, kAtaTilesCorr><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
         else ug::ata_kernel<16, 8, kAtaTilesCorr><<<grid, 512, lds(8), c.stream>>>(c.d_wins, which, nw, ng);
       } else {
-        if (npad <= 256) ug::ata_kernel<4, 32, kAtaTilesLm><<<grid, 512, lds(32), c.stream>>>(c.d_wins, which, nw, ng);  // 107 KB of LDS: half the barriers
+        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesLm><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
         else ug::ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);  // n = 3S <= 480
       }
     };
