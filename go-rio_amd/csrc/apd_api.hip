@@ -66,6 +66,7 @@ struct gorio_apd {
   int desc_cap = 0;
   PairState* d_states_batch = nullptr;
   KnnJob* d_jobs = nullptr;
+  size_t fit_cap = 0;           // doubles in d_fit
   void* d_copy_jobs = nullptr;  // gorio_apd_set_clouds_device_batch
   size_t copy_jobs_cap = 0;
   int jobs_cap = 0;
@@ -1003,6 +1004,12 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
   HIP_TRY(h, hipSetDevice(h->device));
   int rc = ensure_points(h, h->src.n);
   if (rc) return rc;
+  const bool pruned = h->params.search == GORIO_SEARCH_PRUNED;
+  if (pruned) {  // the same exact branch-and-bound search as the registration (matters for 100 k-point maps)
+    std::vector<std::pair<gorio_apd*, DevCloud*>> both = {{h, &h->src}, {h, &h->tgt}};
+    rc = run_index_build(h, both);
+    if (rc) return rc;
+  }
   rc = single_desc(h);
   if (rc) return rc;
   PairState s;
@@ -1010,20 +1017,43 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
   for (int i = 0; i < 16; ++i) Td[i] = (double)T[i];
   init_state(s, Td);
   for (int i = 0; i < 12; ++i) s.Tf[i] = T[i];
+  const int nbx = (h->src.n + 255) / 256;
+  if ((size_t)nbx * 3 > h->fit_cap) {
+    hipFree(h->d_fit);
+    h->d_fit = nullptr;
+    h->fit_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_fit, sizeof(double) * 3 * nbx));
+    h->fit_cap = (size_t)nbx * 3;
+  }
   HIP_TRY(h, hipMemcpyAsync(h->d_state, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->best_key, 0xff, sizeof(unsigned long long) * h->src.n, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_fit, 0, sizeof(double) * 4, h->stream));
   PairDesc d;
   fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
-  const int nbx = (h->src.n + 255) / 256;
-  nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
   const double thr = h->params.corr_dist_threshold;
+  if (pruned) {
+    // nothing farther than max(max_range, gate) is counted by either statistic: that is the search bound (rounded up to a float)
+    const double lim = std::max(max_range, thr * thr);
+    float bf = FLT_MAX;
+    if (lim < (double)FLT_MAX) {
+      bf = (float)lim;
+      if ((double)bf < lim) bf = std::nextafterf(bf, FLT_MAX);
+    }
+    const int waves = (h->src.n + 63) / 64;
+    int splits = 4096 / (waves > 0 ? waves : 1);
+    splits = std::min(16, std::max(1, splits));
+    nn_search_pruned_kernel<<<dim3((roundup(h->src.n, 512) + 255) / 256, splits, 1), 256, 0, h->stream>>>(h->d_desc, bf);
+  } else {
+    nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
+  }
   fitness_kernel<<<nbx, 256, 0, h->stream>>>(h->best_key, h->src.n, max_range, thr * thr, h->d_fit);
   HIP_TRY(h, hipGetLastError());
-  double out[4];
-  HIP_TRY(h, hipMemcpyAsync(out, h->d_fit, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> part((size_t)nbx * 3);
+  HIP_TRY(h, hipMemcpyAsync(part.data(), h->d_fit, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->corr_valid = false;
+  double out[3] = {0.0, 0.0, 0.0};
+  for (int bk = 0; bk < nbx; ++bk)
+    for (int q = 0; q < 3; ++q) out[q] += part[(size_t)bk * 3 + q];
   *score = out[1] > 0 ? out[0] / out[1] : DBL_MAX;  // pcl: returns max double when no correspondence is in range
   if (inlier_fraction) *inlier_fraction = out[2] / (double)h->src.n;
   return GORIO_OK;

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void transform_cloud_kernel(const float* __res
 }
 
 // getFitnessScore / inlier fraction from the packed NN keys of a search at the final transformation
-__global__ __launch_bounds__(256) void fitness_kernel(unsigned long long* __restrict__ best_key, int n, double max_range_sq, double inlier_sq, double* __restrict__ out /* [sum, count, inliers] */) {
+__global__ __launch_bounds__(256) void fitness_kernel(unsigned long long* __restrict__ best_key, int n, double max_range_sq, double inlier_sq, double* __restrict__ out /* [blocks][3]: sum, count, inliers */) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   double s = 0.0, c = 0.0, inl = 0.0;
   if (i < n) {
@@ -812,11 +812,15 @@ __global__ __launch_bounds__(256) void fitness_kernel(unsigned long long* __rest
   s = wave_sum(s);
   c = wave_sum(c);
   inl = wave_sum(inl);
+  __shared__ double sw[4][3];
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(out + 0, s);
-    atomicAdd(out + 1, c);
-    atomicAdd(out + 2, inl);
+    sw[threadIdx.x >> 6][0] = s;
+    sw[threadIdx.x >> 6][1] = c;
+    sw[threadIdx.x >> 6][2] = inl;
   }
+  __syncthreads();
+  if (threadIdx.x < 3)  // one partial per block, added in block order on the host: the score is reproducible run to run
+    out[(size_t)blockIdx.x * 3 + threadIdx.x] = (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
 }
 
 }  // namespace gorio

@@ -284,6 +284,20 @@ def test_transform_source_and_fitness(gpu, gorio, oracle_apd):
     assert inl == pytest.approx(float(np.mean(sqd_o.astype(np.float64) < 4.0)), rel=1e-12)
 
 
+def test_fitness_score_pruned_equals_brute_force(gpu, gorio):
+    """getFitnessScore / the inlier fraction through the pruned search: the same numbers as the exhaustive search, for an
+    unlimited and for a tight max_range (pcl compares the SQUARED distance with max_range)."""
+    sx, sl, tx, tl, T = synth.scan_pair(5000, 4500, seed=13)
+    Tf = T.astype(np.float32)
+    gb = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, search=0)
+    gp = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, search=1)
+    for max_range in (None, 0.5, 9.0):
+        a = gb.getFitnessScore(Tf) if max_range is None else gb.getFitnessScore(Tf, max_range)
+        b = gp.getFitnessScore(Tf) if max_range is None else gp.getFitnessScore(Tf, max_range)
+        assert a == b, (max_range, a, b)
+    assert gp.getFitnessScore(Tf, 0.5)[0] < gp.getFitnessScore(Tf, 9.0)[0]
+
+
 def test_16k_properties(gpu, gorio, pose_err):
     """BASELINE size (16 384 x 16 384): size-independent properties instead of an O(n^2) oracle run.
     (1) identity on identical clouds; (2) a rigidly moved copy is recovered to 1e-4; (3) H is symmetric PSD;
