@@ -1271,22 +1271,39 @@ __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ 
   const double* Ki = w.Kinv + (size_t)ch * S * S;
   const double l2 = w.hyper[ch * 4 + 0], sf2 = w.hyper[ch * 4 + 1];
   const bool integral = (kind == 1 || kind == 2);
-  __shared__ double ks[kCrossRows][160];
+  constexpr int LDK = 164;  // row stride of the staged kernel rows: 4 doubles past a multiple of 32 banks
+  __shared__ double ks[kCrossRows][LDK];
   const int row0 = blockIdx.z * kCrossRows;
   if (row0 >= N) return;
-  for (int q = threadIdx.x; q < kCrossRows * S; q += blockDim.x) {
-    const int r = q / S, k = q % S;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int r = wave; r < kCrossRows; r += 4) {  // kernel rows k(t_n, state_t[.]) of this tile; rows past N and columns past S are zero
     const int n = row0 + r;
-    if (n < N) ks[r][k] = integral ? se_kint(w.start_t, tt[n], w.state_t[k], l2, sf2) : se_k(tt[n], w.state_t[k], l2, sf2);
+    for (int k = lane; k < LDK; k += 64) {
+      double v = 0.0;
+      if (n < N && k < S) v = integral ? se_kint(w.start_t, tt[n], w.state_t[k], l2, sf2) : se_k(tt[n], w.state_t[k], l2, sf2);
+      ks[r][k] = v;
+    }
   }
   __syncthreads();
-  for (int q = threadIdx.x; q < kCrossRows * S; q += blockDim.x) {
-    const int r = q / S, j = q % S;
-    const int n = row0 + r;
-    if (n >= N) continue;
-    double s = 0.0;
-    for (int k = 0; k < S; ++k) s += ks[r][k] * Ki[(size_t)k * S + j];
-    out[(size_t)n * S + j] = s;
+  // out tile = ks (32 x S) . K^-1 (S x S) on the matrix cores: 2 x ceil(S / 16) tiles dealt to the 4 waves
+  const int lr = lane & 15, lk = lane >> 4;
+  const int TJ = (S + 15) / 16;
+  for (int q = wave; q < 2 * TJ; q += 4) {
+    const int ti = q / TJ, tj = q - ti * TJ;
+    const int j = tj * 16 + lr;
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < S; k0 += 4) {
+      const int k = k0 + lk;
+      const double av = ks[ti * 16 + lr][k];  // zero for k >= S
+      const double bv = (k < S && j < S) ? Ki[(size_t)k * S + j] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int n = row0 + ti * 16 + lk + 4 * rg;
+      if (n < N && j < S) out[(size_t)n * S + j] = acc[rg];
+    }
   }
 }
 
