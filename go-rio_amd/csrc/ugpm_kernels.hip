@@ -1108,6 +1108,7 @@ __device__ __forceinline__ void blocked_lower_solve16(const double* __restrict__
       const int c = lane;
       double x[16];
       double* xi = Xc + (size_t)(i - jb) * 16 * 17;
+      const double dinv = 1.0 / sh.Dl[c][c];  // lane c: reciprocal of diagonal entry c, one division off the 16-step chain
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const double bsum = ((sh.Pt[0][r][c] + sh.Pt[1][r][c]) + sh.Pt[2][r][c]) + sh.Pt[3][r][c];
@@ -1115,7 +1116,7 @@ __device__ __forceinline__ void blocked_lower_solve16(const double* __restrict__
 #pragma unroll
         for (int q = 0; q < 16; ++q)
           if (q < r) v = __builtin_fma(-sh.Dl[r][q], x[q], v);
-        v = v / sh.Dl[r][r];
+        v = v * readlane_f64(dinv, r);
         x[r] = (r < nb) ? v : 0.0;
       }
 #pragma unroll
