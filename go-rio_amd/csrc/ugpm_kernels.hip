@@ -1376,6 +1376,27 @@ __device__ __forceinline__ void wave_row_dots6(const double* __restrict__ a, siz
   for (int q = 0; q < 6; ++q) out[q] = t[q];
 }
 
+// three table rows (stride apart) against v + c S, by one wave; results in every lane
+__device__ __forceinline__ void wave_row_dots3(const double* __restrict__ a, size_t a_stride, const double* __restrict__ va, int S, double (&out)[3]) {
+  double t[3] = {0.0, 0.0, 0.0};
+  for (int j = threadIdx.x & 63; j < S; j += 64) {
+    double ra[3], xa[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ra[c] = a[c * a_stride + j];
+      xa[c] = va[(size_t)c * S + j];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] += ra[c] * xa[c];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) t[q] += __shfl_xor(t[q], off, 64);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) out[q] = t[q];
+}
+
 // Acceptance test of a trust-region step (Ceres 2.1 TrustRegionMinimizer: tolerances of preint.h:943-948, rho > 1e-3, radius
 // update), evaluated from the candidate residuals res_new.  It is fused into the kernels that re-linearise after the step, whose
 // grid has several workgroups per window: EVERY workgroup evaluates the (deterministic) decision for itself from inputs none of
@@ -1554,19 +1575,35 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
     const int cnt = min(256, i_hi - ib);
     for (int q = (int)(threadIdx.x >> 6); q < cnt; q += (int)(blockDim.x >> 6)) {
       const int i = ib + q;
-      double d[6];  // 0..2 vel_rot_vec, 3..5 velocity
-      wave_row_dots6(w.KgyrIntKinv + (size_t)i * S, (size_t)V * S, w.s_dr, w.KvelKinv + (size_t)i * S, (size_t)V * S, x, S, d);
-      if ((threadIdx.x & 63) == 0) {
+      // 0..2 vel_rot_vec, 3..5 velocity.  The rotation states are constants of this problem, so R(t)^T of every sample is computed
+      // once (mode 2, kept in sample_tmp) and candidate evaluations (mode 0) only need the three velocity dot products.
+      if (mode == 0) {
+        double d3[3];
+        wave_row_dots3(w.KvelKinv + (size_t)i * S, (size_t)V * S, x, S, d3);
+        if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int q2 = 0; q2 < 6; ++q2) sdot[q][q2] = d[q2];
+          for (int q2 = 0; q2 < 3; ++q2) sdot[q][3 + q2] = d3[q2];
+        }
+      } else {
+        double d[6];
+        wave_row_dots6(w.KgyrIntKinv + (size_t)i * S, (size_t)V * S, w.s_dr, w.KvelKinv + (size_t)i * S, (size_t)V * S, x, S, d);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+          for (int q2 = 0; q2 < 6; ++q2) sdot[q][q2] = d[q2];
+        }
       }
     }
     __syncthreads();
     for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
       const int i = ib + q;
-      const double dtm = w.vel_t[i] - w.start_t;
-      const V3 rv = v3(sdot[q][0] + dtm * w.hyper[3], sdot[q][1] + dtm * w.hyper[7], sdot[q][2] + dtm * w.hyper[11]);
-      const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
+      M3 RT;
+      if (mode == 0) {
+        RT = loadM(w.sample_tmp + (size_t)i * 24);
+      } else {
+        const double dtm = w.vel_t[i] - w.start_t;
+        const V3 rv = v3(sdot[q][0] + dtm * w.hyper[3], sdot[q][1] + dtm * w.hyper[7], sdot[q][2] + dtm * w.hyper[11]);
+        RT = expMap(v3(-rv.x, -rv.y, -rv.z));
+      }
       const V3 vv = v3(sdot[q][3] + w.hyper[15], sdot[q][4] + w.hyper[19], sdot[q][5] + w.hyper[23]);
       const V3 t = mvec(RT, vv);
       double* r = res + 3 * i;
