@@ -575,7 +575,7 @@ __device__ __forceinline__ void topk_insert_key(unsigned long long (&L)[K], unsi
 // self k-NN, pruned, fused with the covariance estimation of APD:366-407 (covariance_from_list).
 // grid: (ceil(n_spad / 256), 1, clouds), block 256.
 template <int K>
-__global__ __launch_bounds__(256) void knn_pruned_kernel(const KnnJob* __restrict__ jobs) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void knn_pruned_kernel(const KnnJob* __restrict__ jobs) {
   const KnnJob& job = jobs[blockIdx.z];
   const SearchIndex& si = job.cloud.idx;
   const int n = si.n;
