@@ -398,7 +398,7 @@ __device__ __forceinline__ double residual_terms(const double* __restrict__ T, f
 
 // grid: (ceil(max_n/256), 1, pairs).  Consumes (and re-arms) best_key, writes corr / sqd / omega6 and one 28-double
 // partial per block: [0..20] upper triangle of H row-major, [21..26] b, [27] weighted error.
-__global__ __launch_bounds__(256) void linearize_kernel(const PairDesc* __restrict__ descs, ApdConsts cst) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void linearize_kernel(const PairDesc* __restrict__ descs, ApdConsts cst) {
   const PairDesc& pd = descs[blockIdx.z];
   PairState* __restrict__ st = pd.state;
   if (st->done) return;
