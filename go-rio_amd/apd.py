@@ -273,10 +273,11 @@ class ApdGicp:
         _check(self._h, self._lib.gorio_apd_transform_source(self._h, _p(T, C.c_float), _p(out, C.c_float), self._n_src, 12))
         return out
 
-    def getFitnessScore(self, T=None, max_range=np.finfo(np.float64).max):  # noqa: N802
+    def getFitnessScore(self, T=None, max_range=np.finfo(np.float64).max, inlier_dist=0.5):  # noqa: N802
+        """(pcl getFitnessScore(max_range), inlier fraction of scan_matching_odometry_nodelet.cpp:677-689 with its 0.5 m bound)."""
         T = np.ascontiguousarray(self._final if T is None else T, np.float32)
         score, inl = C.c_double(0.0), C.c_double(0.0)
-        _check(self._h, self._lib.gorio_apd_fitness_score(self._h, _p(T, C.c_float), C.c_double(max_range), C.byref(score), C.byref(inl)))
+        _check(self._h, self._lib.gorio_apd_fitness_score(self._h, _p(T, C.c_float), C.c_double(max_range), C.c_double(inlier_dist), C.byref(score), C.byref(inl)))
         return score.value, inl.value
 
     def setProfiling(self, on):  # noqa: N802

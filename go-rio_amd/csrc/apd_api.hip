@@ -998,7 +998,7 @@ int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out
   return GORIO_OK;
 }
 
-int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double* score, double* inlier_fraction) {
+int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double inlier_dist, double* score, double* inlier_fraction) {
   if (!h || !T || !score) return GORIO_ERR_INVALID;
   if (!h->src.present || !h->tgt.present) return fail(h, GORIO_ERR_STATE, "fitness_score: clouds not set");
   HIP_TRY(h, hipSetDevice(h->device));
@@ -1029,10 +1029,11 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
   HIP_TRY(h, hipMemsetAsync(h->best_key, 0xff, sizeof(unsigned long long) * h->src.n, h->stream));
   PairDesc d;
   fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
-  const double thr = h->params.corr_dist_threshold;
+  if (!(inlier_dist > 0.0)) inlier_dist = 0.5;  // const double max_correspondence_dist = 0.5, SMO:677
+  const double inlier_sq = inlier_dist * inlier_dist;
   if (pruned) {
-    // nothing farther than max(max_range, gate) is counted by either statistic: that is the search bound (rounded up to a float)
-    const double lim = std::max(max_range, thr * thr);
+    // nothing farther than max(max_range, inlier_dist^2) is counted by either statistic: that is the search bound (rounded up to a float)
+    const double lim = std::max(max_range, inlier_sq);
     float bf = FLT_MAX;
     if (lim < (double)FLT_MAX) {
       bf = (float)lim;
@@ -1045,7 +1046,7 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
   } else {
     nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
   }
-  fitness_kernel<<<nbx, 256, 0, h->stream>>>(h->best_key, h->src.n, max_range, thr * thr, h->d_fit);
+  fitness_kernel<<<nbx, 256, 0, h->stream>>>(h->best_key, h->src.n, max_range, inlier_sq, h->d_fit);
   HIP_TRY(h, hipGetLastError());
   std::vector<double> part((size_t)nbx * 3);
   HIP_TRY(h, hipMemcpyAsync(part.data(), h->d_fit, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));

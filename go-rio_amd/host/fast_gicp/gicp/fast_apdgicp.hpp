@@ -13,6 +13,7 @@
 #define FAST_GICP_FAST_APDGICP_HPP
 
 #include <cfloat>
+#include <cmath>
 #include <iostream>
 #include <limits>
 #include <memory>
@@ -144,8 +145,18 @@ public:
     float T[16];
     to_row_major(final_transformation_, T);
     double score = 0.0;
-    check(gorio_apd_fitness_score(handle_, T, max_range, &score, nullptr));
+    check(gorio_apd_fitness_score(handle_, T, max_range, 0.0, &score, nullptr));
     return score;
+  }
+  // the inlier loop of publish_scan_matching_status (SMO:677-689) on the GPU: share of source points whose squared NN distance in
+  // the target, after final_transformation_, is below max_correspondence_dist^2 (the nodelet hard-codes 0.5 m); float like SMO:689
+  float getInlierFraction(double max_correspondence_dist = 0.5) {
+    float T[16];
+    to_row_major(final_transformation_, T);
+    double score = 0.0, frac = 0.0;
+    check(gorio_apd_fitness_score(handle_, T, 0.0, max_correspondence_dist, &score, &frac));
+    const std::size_t n = input_ ? input_->size() : 0;
+    return n ? static_cast<float>(std::llround(frac * static_cast<double>(n))) / n : 0.0f;
   }
   // extras (not in the reference): correspondences of the last linearisation, device handle
   void getCorrespondences(std::vector<int>& corr, std::vector<float>& sq_dist) {

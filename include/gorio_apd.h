@@ -146,9 +146,12 @@ int gorio_apd_get_mahalanobis(gorio_apd_t* h, double* maha4x4, int n);
 int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out, int n, int point_stride_bytes);
 
 /* pcl::Registration::getFitnessScore(max_range) as the callers use it (scan_matching_odometry_nodelet.cpp:675,
- * loop_detector.cpp:411): mean squared NN distance (<= max_range) of the source moved by T; also the inlier fraction
- * of publish_scan_matching_status (SMO:679-689) when inlier_fraction != NULL. */
-int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double* score, double* inlier_fraction);
+ * loop_detector.cpp:411): mean squared NN distance of the source moved by T over the points whose SQUARED distance is <= max_range
+ * (PCL compares the squared distance with max_range), DBL_MAX when no point qualifies.  When inlier_fraction != NULL it also
+ * receives the inlier fraction of publish_scan_matching_status (scan_matching_odometry_nodelet.cpp:677-689): the share of source
+ * points whose squared NN distance is < inlier_dist * inlier_dist.  The nodelet hard-codes max_correspondence_dist = 0.5 m there
+ * (SMO:677); pass inlier_dist <= 0 to get exactly that.  Neither statistic depends on corr_dist_threshold. */
+int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double inlier_dist, double* score, double* inlier_fraction);
 
 /* seconds spent inside device kernels of the last align / align_batch, by stage (HIP events on the launch stream):
  * [0] covariance estimation, [1] correspondence search, [2] linearize, [3] LM/GN solve + error trials; plus launch counts

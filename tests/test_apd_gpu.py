@@ -281,7 +281,15 @@ def test_transform_source_and_fitness(gpu, gorio, oracle_apd):
     z = np.zeros((900, 4, 4))
     corr_o, sqd_o, _ = oracle_apd.update_correspondences(Td, sx, tx, np.zeros((800, 4, 4)), z, p)
     assert score == pytest.approx(float(np.mean(sqd_o.astype(np.float64))), rel=1e-12)
-    assert inl == pytest.approx(float(np.mean(sqd_o.astype(np.float64) < 4.0)), rel=1e-12)
+    # inlier fraction: the nodelet hard-codes max_correspondence_dist = 0.5 m (SMO:677-685), independent of corr_dist_threshold
+    want = float(np.mean(sqd_o.astype(np.float64) < 0.5 * 0.5))
+    assert 0.0 < want < 1.0
+    assert inl == pytest.approx(want, rel=1e-12)
+    assert g.getFitnessScore(T.astype(np.float32), inlier_dist=0.0)[1] == inl  # <= 0 selects the nodelet's constant
+    g.set_params(corr_dist_threshold=float(np.finfo(np.float32).max))
+    assert g.getFitnessScore(T.astype(np.float32))[1] == inl  # the registration gate plays no part
+    _, inl2 = g.getFitnessScore(T.astype(np.float32), inlier_dist=1.5)
+    assert inl2 == pytest.approx(float(np.mean(sqd_o.astype(np.float64) < 2.25)), rel=1e-12) and inl2 > inl
 
 
 def test_fitness_score_pruned_equals_brute_force(gpu, gorio):
@@ -291,10 +299,11 @@ def test_fitness_score_pruned_equals_brute_force(gpu, gorio):
     Tf = T.astype(np.float32)
     gb = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, search=0)
     gp = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, search=1)
-    for max_range in (None, 0.5, 9.0):
-        a = gb.getFitnessScore(Tf) if max_range is None else gb.getFitnessScore(Tf, max_range)
-        b = gp.getFitnessScore(Tf) if max_range is None else gp.getFitnessScore(Tf, max_range)
-        assert a == b, (max_range, a, b)
+    for max_range in (None, 0.5, 9.0, 0.01):
+        for inlier_dist in (0.5, 0.05, 3.0):  # inlier bound below and above max_range: the search bound is the larger of the two
+            a = gb.getFitnessScore(Tf, inlier_dist=inlier_dist) if max_range is None else gb.getFitnessScore(Tf, max_range, inlier_dist)
+            b = gp.getFitnessScore(Tf, inlier_dist=inlier_dist) if max_range is None else gp.getFitnessScore(Tf, max_range, inlier_dist)
+            assert a == b, (max_range, inlier_dist, a, b)
     assert gp.getFitnessScore(Tf, 0.5)[0] < gp.getFitnessScore(Tf, 9.0)[0]
 
 
