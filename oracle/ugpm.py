@@ -65,6 +65,23 @@ def preintegrate(win, infer_t=None, type=UGPM, min_freq=500.0, state_freq=50.0, 
     return [unpack(r) for r in out], d
 
 
+def states(win, state_freq=50.0, correlate=True, overlap=8, gyr_bias=None, vel_bias=None):
+    """Optimised GP states [6, S] (mean-subtracted) and hyper-parameters [6, 4] = (l2, sf2, sz2, mean) of one UGPM window."""
+    gt, g = np.ascontiguousarray(win["gyr_t"], np.float64), np.ascontiguousarray(win["gyr"], np.float64)
+    vt, v = np.ascontiguousarray(win["vel_t"], np.float64), np.ascontiguousarray(win["vel"], np.float64)
+    gb = np.zeros(3) if gyr_bias is None else np.ascontiguousarray(gyr_bias, np.float64)
+    vb = np.zeros(3) if vel_bias is None else np.ascontiguousarray(vel_bias, np.float64)
+    cap = 6 * 4096
+    st = np.zeros(cap)
+    hy = np.zeros((6, 4))
+    err = C.create_string_buffer(512)
+    S = lib().ugpmo_states(_p(gt), _p(g), len(gt), _p(vt), _p(v), len(vt), C.c_double(win["gyr_var"]), C.c_double(win["vel_var"]), C.c_double(win["start_t"]),
+                           C.c_double(win["end_t"]), C.c_double(state_freq), int(bool(correlate)), int(overlap), _p(gb), _p(vb), _p(st), cap, _p(hy), err, 512)
+    if S < 0:
+        raise RuntimeError(err.value.decode() or f"ugpmo_states rc={S}")
+    return st[: 6 * S].reshape(6, S).copy(), hy
+
+
 def se_kernel(x1, x2, l2, sf2):
     x1, x2 = np.ascontiguousarray(x1, np.float64), np.ascontiguousarray(x2, np.float64)
     out = np.zeros((len(x1), len(x2)))

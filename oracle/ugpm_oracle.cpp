@@ -1802,6 +1802,45 @@ int ugpmo_preintegrate(const double* gyr_t, const double* gyr, int n_g, const do
   }
 }
 
+/*
+ * The optimised GP states and hyper-parameters of one UGPM window (for the cross-check against oracle/ugpm_scipy.py): states_out
+ * receives 6 * S doubles (channel-major: d_r x, y, z, vel x, y, z; mean-subtracted as the reference keeps them, PRE:1464-1465),
+ * hyper_out 6 * 4 doubles (l2, sf2, sz2, mean per channel).  Returns S, or -1 (exception text in err) / -2 (cap too small).
+ */
+int ugpmo_states(const double* gyr_t, const double* gyr, int n_g, const double* vel_t, const double* vel, int n_v, double gyr_var, double vel_var, double start_t,
+                 double end_t, double state_freq, int correlate, int overlap, const double* gyr_bias, const double* vel_bias, double* states_out, int states_cap,
+                 double* hyper_out, char* err, int err_cap) {
+  try {
+    using namespace ugpmo;
+    const GyroVelData data = make_data(gyr_t, gyr, n_g, vel_t, vel, n_v, gyr_var, vel_var);
+    PreintPrior prior;
+    for (int i = 0; i < 3; i++) {
+      prior.gyr_bias[i] = gyr_bias ? gyr_bias[i] : 0.0;
+      prior.vel_bias[i] = vel_bias ? vel_bias[i] : 0.0;
+    }
+    Se3Integrator se3(data, start_t, prior, end_t - start_t, state_freq, overlap, correlate != 0);
+    const int S = se3.nb_state_;
+    if (6 * S > states_cap) return -2;
+    for (int c = 0; c < 6; c++) {
+      const VecX& s = c < 3 ? se3.state_d_r_[c] : se3.state_vel_[c - 3];
+      for (int i = 0; i < S; i++) states_out[(size_t)c * S + i] = s[i];
+      if (hyper_out) {
+        hyper_out[c * 4 + 0] = se3.hyper_[c].l2;
+        hyper_out[c * 4 + 1] = se3.hyper_[c].sf2;
+        hyper_out[c * 4 + 2] = se3.hyper_[c].sz2;
+        hyper_out[c * 4 + 3] = se3.hyper_[c].mean;
+      }
+    }
+    return S;
+  } catch (const std::exception& e) {
+    if (err && err_cap > 0) {
+      std::strncpy(err, e.what(), err_cap - 1);
+      err[err_cap - 1] = 0;
+    }
+    return -1;
+  }
+}
+
 // kernel helpers exported for the analytic pinning tests
 void ugpmo_se_kernel(const double* x1, int n1, const double* x2, int n2, double l2, double sf2, double* out) {
   ugpmo::MatX K = ugpmo::seKernel(ugpmo::VecX(x1, x1 + n1), ugpmo::VecX(x2, x2 + n2), l2, sf2);
