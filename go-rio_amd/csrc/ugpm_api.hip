@@ -15,6 +15,7 @@
 
 #include "../../include/gorio_ugpm.h"
 #include "ugpm_kernels.hip"
+#include "ugpm_lpm_out.hip"
 
 using namespace gorio;
 
@@ -35,6 +36,13 @@ struct Ctx {  // per-thread, per-device cached buffers
   int wins_cap = 0;
   int* d_ints = nullptr;  // per window: kWinInts ints (lmi[16], status, ata_cnt[])
   double* d_diag = nullptr;
+  // opt.type = LPM windows (ugpm_lpm_out.hip)
+  double* lpm_ws = nullptr;
+  size_t lpm_ws_cap = 0;
+  int* lpm_ints = nullptr;
+  size_t lpm_ints_cap = 0;
+  ug::LpmOutWin* d_lpm_wins = nullptr;
+  int lpm_wins_cap = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   std::vector<int> ev_stage;
 };
@@ -57,6 +65,7 @@ struct HostWin {
   std::vector<double> state_t;
   int status = 0;
   size_t ws_doubles = 0;
+  bool is_lpm = false;  // opt.type = LPM: handled by ugpm_lpm_out.hip, skipped by every UGPM kernel
 };
 
 // GyroVelData::get(from, to): samples with from < t < to, scanning until the first t >= to (types.h:187-223)
@@ -127,6 +136,64 @@ struct Stage {
   }
 };
 
+// ---- opt.type = LPM (preint.h:1567-1580): host bookkeeping of one IterativeIntegrator = the merged, sorted time line
+// (SortIndexTracker2, types.h:332-458) and the filler stamps of preint.h:228-237.  No numerics.
+struct LpmHost {
+  std::vector<double> tl;
+  std::vector<int> kind, kidx, qpos, qorder, qrot;
+  int start_index = 0, dt_index = 0;
+};
+
+void build_lpm_timeline(const gorio_ugpm_window& w, LpmHost& L) {
+  struct Stamp { double t; int kind, idx; };
+  std::vector<Stamp> st;
+  st.reserve((size_t)w.n_infer + 2 + w.n_vel);
+  for (int j = 0; j < w.n_infer; ++j) st.push_back({w.infer_t[j], 0, j});
+  st.push_back({w.start_t, 1, 0});
+  st.push_back({w.start_t + 0.01, 1, 1});  // kNumDtJacobianDelta, preint.h:216-219
+  for (int i = 0; i < w.n_vel; ++i) st.push_back({w.vel_t[i], 2, i});
+  auto by_time = [](const Stamp& a, const Stamp& b) { return a.t < b.t; };
+  std::stable_sort(st.begin(), st.end(), by_time);
+  // getSmallestGap() returns the LAST gap of the sorted line (types.h:442-450), preint.h:228
+  if (st.size() >= 2 && (st.back().t - st[st.size() - 2].t) > (1.0 / w.min_freq)) {
+    const double first = st.front().t, last = st.back().t;
+    const int nb = (int)std::floor((last - first) * w.min_freq);
+    if (nb > 0) {
+      const double quantum = (last - first) / ((double)nb);
+      for (int i = 0; i < nb; ++i) st.push_back({first + (i * quantum), 3, i});
+      std::stable_sort(st.begin(), st.end(), by_time);
+    }
+  }
+  const size_t T = st.size();
+  L.tl.resize(T); L.kind.resize(T); L.kidx.resize(T);
+  L.qpos.assign(w.n_infer, 0);
+  L.qorder.clear();
+  for (size_t r = 0; r < T; ++r) {
+    L.tl[r] = st[r].t; L.kind[r] = st[r].kind; L.kidx[r] = st[r].idx;
+    if (st[r].kind == 0) { L.qpos[st[r].idx] = (int)r; L.qorder.push_back(st[r].idx); }
+    if (st[r].kind == 1 && st[r].idx == 0) L.start_index = (int)r;
+    if (st[r].kind == 1 && st[r].idx == 1) L.dt_index = (int)r;
+  }
+  // preint_[g] = t.getVector(preint, g) (preint.h:259, types.h:378-387): the rotation part of record k of inner vector g is that of the
+  // vector's k-th stamp IN SORTED ORDER; the position part is written by original index later (preint.h:640-664)
+  L.qrot.assign(w.n_infer, 0);
+  std::vector<int> group_of(w.n_infer, 0), first_of_group(1, 0);
+  if (w.group_sizes && w.n_groups > 0) {
+    int o = 0;
+    first_of_group.clear();
+    for (int g = 0; g < w.n_groups; ++g) {
+      first_of_group.push_back(o);
+      for (int k = 0; k < w.group_sizes[g] && o < w.n_infer; ++k) group_of[o++] = g;
+    }
+  }
+  std::vector<int> filled(first_of_group.size(), 0);
+  for (size_t r = 0; r < T; ++r)
+    if (st[r].kind == 0) {
+      const int g = group_of[st[r].idx];
+      L.qrot[first_of_group[g] + filled[g]++] = (int)r;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,7 +230,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   Ctx& c = g_ctx;
   if (c.device != device) {
     if (c.stream) hipStreamDestroy(c.stream);
-    hipFree(c.ws); hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag);
+    hipFree(c.ws); hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag); hipFree(c.lpm_ws); hipFree(c.lpm_ints); hipFree(c.d_lpm_wins);
     c = Ctx();
     c.device = device;
     bool made = false;
@@ -192,7 +259,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   std::vector<HostWin> hw(n_windows);
   size_t total_doubles = 0, total_in = 0;
   int total_infer = 0, max_infer = 0, max_S = 0;
-  int first_error = 0;
+  int first_error = 0, n_lpm = 0;
   std::string first_error_msg;
   auto win_fail = [&](int i, int code, const std::string& m) {
     hw[i].status = code;
@@ -208,8 +275,24 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     max_infer = std::max(max_infer, w.n_infer);
     if (!w.gyr_t || !w.gyr || !w.vel_t || !w.vel || !w.infer_t || w.n_infer <= 0) { win_fail(i, GORIO_UGPM_ERR_INVALID, "null pointers or no inference time"); continue; }
     if (w.quantum >= 0) { win_fail(i, GORIO_UGPM_ERR_UNSUPPORTED, "chunked pre-integration (opt.quantum > 0, preint.h:1584-1702) is not supported; Go-RIO uses quantum = -1"); continue; }
-    if (w.type != GORIO_UGPM_TYPE_UGPM) { win_fail(i, GORIO_UGPM_ERR_UNSUPPORTED, "only type = UGPM is offloaded (LPM is used internally for initialisation)"); continue; }
+    if (w.type != GORIO_UGPM_TYPE_UGPM && w.type != GORIO_UGPM_TYPE_LPM) { win_fail(i, GORIO_UGPM_ERR_INVALID, "unknown pre-integration type"); continue; }
     if (w.n_gyr < 2 || w.n_vel < 2) { win_fail(i, GORIO_UGPM_ERR_RANGE, "InterpolateLinear: this function need at least 2 data points to interpolate"); continue; }
+    if (w.group_sizes && w.n_groups > 0) {
+      long tot = 0;
+      for (int g = 0; g < w.n_groups; ++g) tot += w.group_sizes[g] < 0 ? -(1L << 40) : w.group_sizes[g];
+      if (tot != w.n_infer) { win_fail(i, GORIO_UGPM_ERR_INVALID, "group_sizes do not add up to n_infer"); continue; }
+    }
+    if (w.type == GORIO_UGPM_TYPE_LPM) {  // preint.h:1567-1580: IterativeIntegrator over the WHOLE data set, no state window
+      if (!(w.min_freq > 0.0)) { win_fail(i, GORIO_UGPM_ERR_INVALID, "min_freq must be positive"); continue; }
+      bool any = false;
+      for (int j = 0; j < w.n_infer; ++j) any = any || (w.infer_t[j] >= w.start_t);
+      if (!any) { win_fail(i, GORIO_UGPM_ERR_RANGE, "FullLPM: the start_time is not in the query domain"); continue; }  // preint.h:559
+      h.is_lpm = true;
+      h.G = w.n_gyr;
+      h.V = w.n_vel;
+      n_lpm++;
+      continue;
+    }
     const double vel_freq = (w.n_vel - 1) / (w.vel_t[w.n_vel - 1] - w.vel_t[0]);
     const double gyr_freq = (w.n_gyr - 1) / (w.gyr_t[w.n_gyr - 1] - w.gyr_t[0]);
     const double duration = *std::max_element(w.infer_t, w.infer_t + w.n_infer) - w.start_t;  // preint.h:1544-1552
@@ -274,6 +357,11 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     u.out = out_region + out_off;
     out_off += (size_t)u.n_infer * 83;
     if (h.status != 0) continue;
+    if (h.is_lpm) {
+      ints[kWinInts * (size_t)i + 16] = 1;  // every UGPM kernel skips this window; its own status word is slot 17
+      u.n_infer = 0;                        // and infer_kernel writes nothing for it
+      continue;
+    }
     carve(w, h, u, base, in_region + in_off, u.out);
     const size_t S = h.S, G = h.G, V = h.V;
     u.G = h.G; u.V = h.V; u.S = h.S;
@@ -301,14 +389,113 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   if (total_in) UHIP(hipMemcpyAsync(in_region, stage_in.data(), sizeof(double) * total_in, hipMemcpyHostToDevice, c.stream));
   UHIP(hipMemcpyAsync(c.d_wins, dw.data(), sizeof(UgpmWin) * n_windows, hipMemcpyHostToDevice, c.stream));
   UHIP(hipMemcpyAsync(c.d_ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice, c.stream));
+  UHIP(hipMemsetAsync(c.d_diag, 0, sizeof(double) * 4 * n_windows, c.stream));  // windows no solver touches report zero iterations
   tt1 = tnow();
   // no synchronisation here: the three staging vectors outlive every use of them (they are locals of this call, which ends with a
   // stream synchronisation), and the kernels below are ordered behind the copies on the same stream
   tt2 = tnow();
 
+  // ---- opt.type = LPM windows: their own workspace and three launches (ugpm_lpm_out.hip)
+  std::vector<ug::LpmOutWin> lw;
+  std::vector<double> lpm_in;
+  std::vector<int> lpm_ints_h;
+  if (n_lpm > 0) {
+    std::vector<LpmHost> lh(n_lpm);
+    std::vector<int> widx;
+    size_t dbl = 0, in_dbl = 0, nint = 0;
+    int max_T = 2;
+    for (int i = 0; i < n_windows; ++i) {
+      if (!hw[i].is_lpm || hw[i].status != 0) continue;
+      LpmHost& L = lh[widx.size()];
+      build_lpm_timeline(windows[i], L);
+      widx.push_back(i);
+      const size_t T = L.tl.size(), G = windows[i].n_gyr, V = windows[i].n_vel, Q = windows[i].n_infer;
+      max_T = std::max(max_T, (int)T);
+      in_dbl += 4 * G + 4 * V + Q + T;
+      dbl += 45 * T + 9 * T + 9 * T + 3 * T + 9 * T + 3 * V + 18 * V + 3 * V + 3 * Q + 8;
+      nint += 2 * T + 3 * Q;
+    }
+    if (in_dbl + dbl > c.lpm_ws_cap) {
+      hipFree(c.lpm_ws);
+      c.lpm_ws = nullptr;
+      c.lpm_ws_cap = 0;
+      UHIP(hipMalloc(&c.lpm_ws, sizeof(double) * (in_dbl + dbl)));
+      c.lpm_ws_cap = in_dbl + dbl;
+    }
+    if (nint > c.lpm_ints_cap) {
+      hipFree(c.lpm_ints);
+      c.lpm_ints = nullptr;
+      c.lpm_ints_cap = 0;
+      UHIP(hipMalloc(&c.lpm_ints, sizeof(int) * nint));
+      c.lpm_ints_cap = nint;
+    }
+    if (n_lpm > c.lpm_wins_cap) {
+      hipFree(c.d_lpm_wins);
+      c.d_lpm_wins = nullptr;
+      UHIP(hipMalloc(&c.d_lpm_wins, sizeof(ug::LpmOutWin) * n_lpm));
+      c.lpm_wins_cap = n_lpm;
+    }
+    lw.resize(widx.size());
+    lpm_in.assign(in_dbl, 0.0);
+    lpm_ints_h.assign(nint, 0);
+    double* din = c.lpm_ws;           // inputs of all LPM windows, one upload
+    double* dsc = c.lpm_ws + in_dbl;  // scratch
+    size_t io = 0, so = 0, no = 0;
+    for (size_t k = 0; k < widx.size(); ++k) {
+      const int i = widx[k];
+      const gorio_ugpm_window& w = windows[i];
+      const LpmHost& L = lh[k];
+      const size_t T = L.tl.size(), G = w.n_gyr, V = w.n_vel, Q = w.n_infer;
+      ug::LpmOutWin& u = lw[k];
+      std::memset(&u, 0, sizeof(u));
+      double* hin = lpm_in.data() + io;
+      auto take_in = [&](size_t cnt) { const double* r = din + io; io += cnt; return r; };
+      auto take = [&](size_t cnt) { double* r = dsc + so; so += cnt; return r; };
+      u.gyr_t = take_in(G); u.gyr = take_in(3 * G); u.vel_t = take_in(V); u.vel = take_in(3 * V); u.infer_t = take_in(Q); u.tl = take_in(T);
+      for (size_t q = 0; q < G; ++q) hin[q] = w.gyr_t[q];
+      hin += G;
+      for (int a = 0; a < 3; ++a)
+        for (size_t q = 0; q < G; ++q) hin[a * G + q] = w.gyr[3 * q + a];
+      hin += 3 * G;
+      for (size_t q = 0; q < V; ++q) hin[q] = w.vel_t[q];
+      hin += V;
+      for (int a = 0; a < 3; ++a)
+        for (size_t q = 0; q < V; ++q) hin[a * V + q] = w.vel[3 * q + a];
+      hin += 3 * V;
+      for (size_t q = 0; q < Q; ++q) hin[q] = w.infer_t[q];
+      hin += Q;
+      for (size_t q = 0; q < T; ++q) hin[q] = L.tl[q];
+      int* hi = lpm_ints_h.data() + no;
+      u.kind = c.lpm_ints + no; u.kidx = c.lpm_ints + no + T; u.qpos = c.lpm_ints + no + 2 * T; u.qorder = c.lpm_ints + no + 2 * T + Q; u.qrot = c.lpm_ints + no + 2 * T + 2 * Q;
+      for (size_t q = 0; q < T; ++q) { hi[q] = L.kind[q]; hi[T + q] = L.kidx[q]; }
+      for (size_t q = 0; q < Q; ++q) { hi[2 * T + q] = L.qpos[q]; hi[2 * T + Q + q] = L.qorder[q]; hi[2 * T + 2 * Q + q] = L.qrot[q]; }
+      no += 2 * T + 3 * Q;
+      u.G = (int)G; u.V = (int)V; u.T = (int)T; u.n_infer = (int)Q;
+      u.start_index = L.start_index; u.dt_index = L.dt_index;
+      u.start_t = w.start_t; u.gyr_var = w.gyr_var; u.vel_var = w.vel_var;
+      for (int a = 0; a < 3; ++a) { u.gyr_bias[a] = w.gyr_bias[a]; u.vel_bias[a] = w.vel_bias[a]; }
+      u.vel_bias_std = w.vel_bias_std; u.gyr_bias_std = w.gyr_bias_std;
+      u.E = take(45 * T); u.B = take(9 * T); u.cov3 = take(9 * T); u.dRdt = take(3 * T); u.dRdbw = take(9 * T);
+      u.velr = take(3 * V); u.d_bw = take(18 * V); u.d_dt = take(3 * V); u.dp_shift = take(3 * Q);
+      u.out = dw[i].out;
+      u.status = c.d_ints + kWinInts * (size_t)i + 17;
+    }
+    UHIP(hipMemcpyAsync(c.lpm_ws, lpm_in.data(), sizeof(double) * in_dbl, hipMemcpyHostToDevice, c.stream));
+    UHIP(hipMemcpyAsync(c.lpm_ints, lpm_ints_h.data(), sizeof(int) * nint, hipMemcpyHostToDevice, c.stream));
+    UHIP(hipMemcpyAsync(c.d_lpm_wins, lw.data(), sizeof(ug::LpmOutWin) * lw.size(), hipMemcpyHostToDevice, c.stream));
+    const int nl = (int)lw.size();
+    if (nl > 0) {
+      Stage st(c, 0);
+      ug::lpm_out_steps_kernel<<<dim3((max_T + 255) / 256, 5, nl), 256, 0, c.stream>>>(c.d_lpm_wins);
+      ug::lpm_out_scan_kernel<<<dim3(5, nl), 64, 0, c.stream>>>(c.d_lpm_wins);
+      ug::lpm_out_finish_kernel<<<nl, 256, 0, c.stream>>>(c.d_lpm_wins);
+      UHIP(hipGetLastError());
+    }
+  }
+
   const int nw = n_windows;
-  const int max_G = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.G); return m; }();
-  const int max_V = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.V); return m; }();
+  const int max_G = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.is_lpm ? 2 : h.G); return m; }();
+  const int max_V = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.is_lpm ? 2 : h.V); return m; }();
   if (max_S > 0) {
     // J^T J launches: one workgroup per (row slice, tile group, window), see ata_kernel
     auto launch_ata = [&](int which) {
@@ -403,7 +590,11 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       double* o = reinterpret_cast<double*>(out) + out_offs[i];
       for (size_t k = 0; k < (size_t)std::max(0, windows[i].n_infer) * 83; ++k) o[k] = std::numeric_limits<double>::quiet_NaN();
     }
-    int st = hw[i].status != 0 ? hw[i].status : fin[kWinInts * (size_t)i + 16];
+    int st = hw[i].status != 0 ? hw[i].status : fin[kWinInts * (size_t)i + (hw[i].is_lpm ? 17 : 16)];
+    if (hw[i].is_lpm && hw[i].status == 0 && st != 0) {  // the LPM kernels stop mid-way on a data-domain error: no partial records
+      double* o = reinterpret_cast<double*>(out) + out_offs[i];
+      for (size_t k = 0; k < (size_t)std::max(0, windows[i].n_infer) * 83; ++k) o[k] = std::numeric_limits<double>::quiet_NaN();
+    }
     if (st != 0 && hw[i].status == 0 && !first_error) {
       first_error = st;
       first_error_msg = "window " + std::to_string(i) + (st == GORIO_UGPM_ERR_NUMERIC ? ": Cholesky factorisation met a non-positive pivot" : ": LPM Partial: the start_time is not in the data domain");

@@ -36,7 +36,11 @@ public:
       for (int a = 0; a < 3; ++a) v[3 * i + a] = imu_data.vel[i].data[a];
     }
     std::vector<double> flat;
-    for (const auto& grp : infer_t) flat.insert(flat.end(), grp.begin(), grp.end());
+    std::vector<int> group_sizes;
+    for (const auto& grp : infer_t) {
+      flat.insert(flat.end(), grp.begin(), grp.end());
+      group_sizes.push_back(static_cast<int>(grp.size()));
+    }
     gorio_ugpm_window w;
     gorio_ugpm_default_window(&w);
     w.gyr_t = gt.data(); w.gyr = g.data(); w.n_gyr = static_cast<int>(gt.size());
@@ -49,6 +53,7 @@ public:
     w.correlate = opt.correlate ? 1 : 0; w.overlap = overlap;
     for (int a = 0; a < 3; ++a) { w.gyr_bias[a] = prior.gyr_bias[a]; w.vel_bias[a] = prior.vel_bias[a]; }
     w.vel_bias_std = 0.0; w.gyr_bias_std = 0.0;
+    w.group_sizes = group_sizes.data(); w.n_groups = static_cast<int>(group_sizes.size());
     std::vector<gorio_ugpm_meas> out(flat.size());
     const int rc = gorio_ugpm_preint_batch(&w, 1, out.data(), nullptr, device);
     if (rc != GORIO_UGPM_OK) {

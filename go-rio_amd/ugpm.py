@@ -28,6 +28,7 @@ class UgpmWindow(C.Structure):
         ("correlate", C.c_int), ("overlap", C.c_int),
         ("gyr_bias", C.c_double * 3), ("vel_bias", C.c_double * 3),
         ("vel_bias_std", C.c_double), ("gyr_bias_std", C.c_double),
+        ("group_sizes", C.c_void_p), ("n_groups", C.c_int),
     ]
 
 
@@ -55,7 +56,7 @@ class UgpmBatch:
     both transfers, happens inside it, every time."""
 
     def __init__(self, windows, device=0, infer_t=None, type=UGPM, state_freq=50.0, correlate=True, overlap=8, quantum=-1.0, min_freq=500.0,
-                 gyr_bias=None, vel_bias=None, vel_bias_std=0.0, gyr_bias_std=0.0):
+                 gyr_bias=None, vel_bias=None, vel_bias_std=0.0, gyr_bias_std=0.0, groups=None):
         lib = load_library()
         lib.gorio_ugpm_last_error.restype = C.c_char_p
         n = len(windows)
@@ -82,6 +83,11 @@ class UgpmBatch:
                 a.gyr_bias[k] = 0.0 if gyr_bias is None else float(gyr_bias[k])
                 a.vel_bias[k] = 0.0 if vel_bias is None else float(vel_bias[k])
             a.vel_bias_std, a.gyr_bias_std = vel_bias_std, gyr_bias_std
+            if groups is not None and groups[i] is not None:  # lengths of the inner vectors of a vector<vector<double>> infer_t
+                gs = np.ascontiguousarray(groups[i], np.int32)
+                assert int(gs.sum()) == len(q)
+                self.keep.append(gs)
+                a.group_sizes, a.n_groups = gs.__array_interface__["data"][0], len(gs)
             self.counts.append(len(q))
         self.out = np.zeros((sum(self.counts), REC))
         self.diag = (UgpmDiag * n)()
@@ -108,11 +114,11 @@ class UgpmBatch:
 
 
 def ugpm_preint_batch(windows, device=0, infer_t=None, type=UGPM, state_freq=50.0, correlate=True, overlap=8, quantum=-1.0, min_freq=500.0,
-                      gyr_bias=None, vel_bias=None, vel_bias_std=0.0, gyr_bias_std=0.0, return_diag=False):
+                      gyr_bias=None, vel_bias=None, vel_bias_std=0.0, gyr_bias_std=0.0, return_diag=False, groups=None):
     """gorio_ugpm_preint_batch over a list of window dicts (as made by synth.imu_window).  `infer_t`: None (each window's end_t) or a
     list of per-window arrays.  Returns a list (per window) of lists (per inference time) of PreintMeas dicts."""
     b = UgpmBatch(windows, device=device, infer_t=infer_t, type=type, state_freq=state_freq, correlate=correlate, overlap=overlap, quantum=quantum,
-                  min_freq=min_freq, gyr_bias=gyr_bias, vel_bias=vel_bias, vel_bias_std=vel_bias_std, gyr_bias_std=gyr_bias_std)
+                  min_freq=min_freq, gyr_bias=gyr_bias, vel_bias=vel_bias, vel_bias_std=vel_bias_std, gyr_bias_std=gyr_bias_std, groups=groups)
     b.run()
     if return_diag:
         return b.results(), b.diagnostics()
@@ -157,7 +163,8 @@ class VelPreintegration:
         win = dict(imu_data)
         win["start_t"] = start_t
         self._args = dict(device=device, infer_t=[flat], type=opt.type, state_freq=opt.state_freq, correlate=opt.correlate, overlap=overlap,
-                          quantum=opt.quantum, min_freq=opt.min_freq, gyr_bias=prior.gyr_bias, vel_bias=prior.vel_bias)
+                          quantum=opt.quantum, min_freq=opt.min_freq, gyr_bias=prior.gyr_bias, vel_bias=prior.vel_bias,
+                          groups=[[len(g) for g in groups]])
         self._win = win
         self._groups = groups
         self._prior = prior

@@ -25,7 +25,7 @@ typedef enum {
   GORIO_UGPM_ERR_NO_DEVICE = -2,   /* no usable HIP device / HIP runtime error */
   GORIO_UGPM_ERR_RANGE = -3,       /* what the reference reports with std::range_error (MATH:493, PRE:680-686, TYPES:415) */
   GORIO_UGPM_ERR_ARGUMENT = -4,    /* std::invalid_argument of GyroVelData::get (TYPES:160) */
-  GORIO_UGPM_ERR_UNSUPPORTED = -5, /* type = LPM as the OUTPUT method, or chunked mode (opt.quantum > 0, PRE:1584-1702) */
+  GORIO_UGPM_ERR_UNSUPPORTED = -5, /* chunked mode (opt.quantum > 0, PRE:1584-1702), more than 160 GP states */
   GORIO_UGPM_ERR_NUMERIC = -6      /* a Cholesky factorisation met a non-positive pivot */
 } gorio_ugpm_status;
 
@@ -50,7 +50,7 @@ typedef struct {
   double start_t;
   const double* infer_t; /* query times; the nodelet passes exactly one (RGS:503-508) */
   int n_infer;
-  int type;           /* gorio_ugpm_type; default UGPM (TYPES:288) */
+  int type;           /* gorio_ugpm_type; default UGPM (TYPES:288).  LPM = IterativeIntegrator as the output method (PRE:1567-1580) over ALL samples given */
   double min_freq;    /* PreintOption::min_freq, default 500 (TYPES:287); the internal LPM passes always use 500 (PRE:1201) */
   double quantum;     /* PreintOption::quantum, default -1 (no chunks); > 0 is unsupported */
   double state_freq;  /* PreintOption::state_freq, default 50 (TYPES:290) */
@@ -60,6 +60,13 @@ typedef struct {
   double vel_bias[3];
   double vel_bias_std; /* arguments of get(): 0.3 / 0.03 by default (PRE:55), 0 / 0 from the nodelet */
   double gyr_bias_std;
+  /* The reference's first constructor takes infer_t as vector<vector<double>> (PRE:1517-1523); here the inner vectors are laid end to
+   * end in infer_t and group_sizes[n_groups] gives their lengths (NULL / 0 = one vector of n_infer stamps).  UGPM evaluates every
+   * stamp on its own, so grouping changes nothing there.  For type = LPM it reproduces a detail of the reference: the rotation part
+   * of record j of a group is that of the group's j-th SMALLEST stamp (SortIndexTracker2::getVector, TYPES:378-387, PRE:259) while
+   * the position part is written by original index (PRE:640-664) -- identical whenever each inner vector is ascending. */
+  const int* group_sizes;
+  int n_groups;
 } gorio_ugpm_window;
 
 /* ugpm::PreintMeas (TYPES:236-281); matrices ROW-major.  83 doubles. */

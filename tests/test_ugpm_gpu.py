@@ -107,3 +107,79 @@ def test_class_surface_and_errors(gpu, gorio, ugpm_oracle):
     short["gyr_t"], short["gyr"] = win["gyr_t"][:1], win["gyr"][:1]
     with pytest.raises(gorio.GorioError):
         gorio.ugpm_preint_batch([short])  # std::range_error in the reference (math_utils.h:493)
+
+
+# ---------------------------------------------------------------------------------------------- LPM as the output method (a8, direct)
+
+@pytest.mark.parametrize("vel_hz", [200.0, 20.0])
+def test_lpm_output_type_matches_oracle(gpu, gorio, ugpm_oracle, vel_hz):
+    """opt.type = LPM (PRE:1567-1580): the device IterativeIntegrator (rotation tables, covariance recursion, numeric Jacobians,
+    velocity re-projection, trapezoid position integration, PRE:170-742) against the oracle's, directly -- no GP fit in between.
+    Also the direct test of SURVEY row a8: the same integrations seed every UGPM window."""
+    win = synth.imu_window(seed=11, vel_hz=vel_hz)
+    q = [win["start_t"] - 0.2, win["start_t"], win["start_t"] + 0.3, win["start_t"] + 0.7, win["end_t"]]  # one query ahead of the start
+    kw = dict(gyr_bias=[0.002, -0.001, 0.003], vel_bias=[0.02, -0.01, 0.0])
+    rg = gorio.ugpm_preint_batch([win], infer_t=[q], type=gorio.ugpm.LPM, **kw)[0]
+    ro, _ = ugpm_oracle.preintegrate(win, infer_t=q, type=0, **kw)
+    assert len(rg) == len(q)
+    for a, b in zip(rg, ro):
+        rot, pos = _cmp(a, b, rot_tol=1e-10, pos_tol=1e-10, cov_rtol=1e-9, jac_rtol=1e-6)
+    assert np.allclose(rg[0]["delta_p"], 0) and rg[0]["dt"] == pytest.approx(-0.2)  # ahead of the start: rotation only (PRE:553-557)
+    assert np.allclose(rg[1]["delta_R"], np.eye(3), atol=1e-15)
+
+
+def test_lpm_output_inflation_min_freq_and_unsorted_queries(gpu, gorio, ugpm_oracle):
+    win = synth.imu_window(seed=12, vel_hz=20.0)
+    # not ascending: the reference then pairs the rotation part of the j-th SMALLEST stamp (getVector, TYPES:378-387) with the position
+    # part of the j-th stamp as given (PRE:640-664); the oracle restates that and the device reproduces it
+    q = [win["end_t"], win["start_t"] + 0.4, win["start_t"] + 0.1]
+    for kw in (dict(vel_bias_std=0.3, gyr_bias_std=0.03), dict(min_freq=100.0), dict(min_freq=2000.0)):
+        rg = gorio.ugpm_preint_batch([win], infer_t=[q], type=gorio.ugpm.LPM, **kw)[0]
+        ro, _ = ugpm_oracle.preintegrate(win, infer_t=q, type=0, **kw)
+        for a, b in zip(rg, ro):
+            _cmp(a, b, rot_tol=1e-10, pos_tol=1e-10, cov_rtol=1e-9, jac_rtol=1e-6)
+
+
+def test_lpm_and_ugpm_windows_mixed_in_one_batch(gpu, gorio, ugpm_oracle):
+    """A batch may mix output types per window (the ABI carries `type` per window): each equals its own single call."""
+    wins = [synth.imu_window(seed=60 + k) for k in range(4)]
+    lib = gorio.load_library()
+    b = gorio.UgpmBatch(wins)
+    for k in (1, 3):
+        b.arr[k].type = gorio.ugpm.LPM
+    rec = b.run().copy()
+    assert all(d["status"] == 0 for d in b.diagnostics())
+    for k, w in enumerate(wins):
+        single = gorio.UgpmBatch([w], type=gorio.ugpm.LPM if k in (1, 3) else gorio.ugpm.UGPM).run()
+        assert np.array_equal(single[0], rec[k]), k
+    mo, _ = ugpm_oracle.preintegrate(wins[1], type=0)
+    _cmp(gorio.ugpm.unpack(rec[1]), mo[0], rot_tol=1e-10, pos_tol=1e-10, cov_rtol=1e-9, jac_rtol=1e-6)
+    del lib
+
+
+def test_lpm_output_errors(gpu, gorio):
+    win = synth.imu_window(seed=13)
+    with pytest.raises(gorio.GorioError) as e:
+        gorio.ugpm_preint_batch([win], infer_t=[[win["start_t"] - 0.3]], type=gorio.ugpm.LPM)  # std::range_error, PRE:559
+    assert e.value.code == -3
+    late = dict(win)
+    late["start_t"] = win["vel_t"][-1] + 0.5  # no velocity segment reaches the start: std::range_error, PRE:565
+    late["end_t"] = late["start_t"] + 0.1
+    with pytest.raises(gorio.GorioError) as e:
+        gorio.ugpm_preint_batch([late], type=gorio.ugpm.LPM)
+    assert e.value.code == -3
+
+
+def test_lpm_output_vector_of_vectors_grouping(gpu, gorio):
+    """infer_t as vector<vector<double>> (PRE:1517-1523) with ascending inner vectors: every record equals the record of the same stamp
+    from one flat ascending vector (one IterativeIntegrator over the same merged time line either way)."""
+    win = synth.imu_window(seed=14)
+    data = {k: win[k] for k in ("gyr_t", "gyr", "vel_t", "vel", "gyr_var", "vel_var")}
+    t0, t1, t2, t3 = (win["start_t"] + d for d in (0.2, 0.5, 0.8, 1.0))
+    opt = gorio.PreintOption(type=gorio.ugpm.LPM)
+    flat = gorio.VelPreintegration(data, win["start_t"], [t0, t1, t2, t3], opt)
+    grouped = gorio.VelPreintegration(data, win["start_t"], [[t0, t2], [t1, t3]], opt)
+    for (i, j), k in {(0, 0): 0, (0, 1): 2, (1, 0): 1, (1, 1): 3}.items():
+        a, b = grouped.get(i, j, vel_bias_std=0.0, gyr_bias_std=0.0), flat.get(k, vel_bias_std=0.0, gyr_bias_std=0.0)
+        for key in a:
+            assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), (i, j, key)
