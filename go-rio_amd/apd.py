@@ -38,6 +38,7 @@ class ApdParams(C.Structure):
         ("lm_init_lambda_factor", C.c_double),
         ("search", C.c_int),
         ("cl_weight_points", C.c_int),
+        ("keep_knn_indices", C.c_int),
     ]
 
 
@@ -284,8 +285,8 @@ class ApdGicp:
         _check(self._h, self._lib.gorio_apd_set_profiling(self._h, int(bool(on))))
 
     def getStageTimes(self):  # noqa: N802
-        s = (C.c_double * 4)()
-        c = (C.c_int * 4)()
+        s = (C.c_double * 8)()
+        c = (C.c_int * 8)()
         _check(self._h, self._lib.gorio_apd_get_stage_times(self._h, s, c))
         return list(s), list(c)
 

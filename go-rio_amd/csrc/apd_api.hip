@@ -27,12 +27,17 @@ constexpr float kFar = 1e30f;
 
 struct DevCloud {
   float *x = nullptr, *y = nullptr, *z = nullptr, *label = nullptr;
+  float4* p4 = nullptr;
   double *cov6 = nullptr, *geo_w = nullptr;
-  int* knn = nullptr;      // [n][k] neighbour indices of the last covariance computation (parity hook)
+  int* knn = nullptr;      // [n][k] neighbour indices of the last covariance computation (parity hook, params.keep_knn_indices)
+  int* redo = nullptr;     // per query wave: redo flags of knn_collect_kernel
+  float* kth = nullptr;    // per sorted position: k-th distance (knn_kth_kernel)
+  int redo_cap = 0;
   float* part_d = nullptr; // k-NN partial lists
   int* part_i = nullptr;
   size_t part_cap = 0;     // elements
   int knn_k = 0;
+  bool knn_valid = false;  // knn holds the lists of the current covariances
   int n = 0, n_pad = 0, cap = 0;
   bool present = false;
   int cov_count = 0;       // == source_covs_.size(): n when valid, 0 when stale
@@ -42,7 +47,7 @@ struct DevCloud {
   unsigned int* bb = nullptr;
   int idx_cap = 0, keys_cap = 0;
   bool idx_valid = false;
-  CloudView view() const { return CloudView{x, y, z, label, cov6, geo_w, n, n_pad, idx}; }
+  CloudView view() const { return CloudView{x, y, z, label, p4, cov6, geo_w, n, n_pad, idx}; }
 };
 
 }  // namespace
@@ -76,8 +81,8 @@ struct gorio_apd {
   std::string err;
   // profiling
   bool profiling = false;
-  double stage_s[4] = {0, 0, 0, 0};
-  int stage_n[4] = {0, 0, 0, 0};
+  double stage_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int stage_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   struct EvPair { hipEvent_t start, stop; int stage; };
   std::vector<EvPair> ev_pool;
   size_t ev_used = 0;
@@ -113,20 +118,21 @@ int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
 void free_cloud(DevCloud& c) {
   hipFree(c.idx.sx); hipFree(c.idx.sy); hipFree(c.idx.sz); hipFree(c.idx.orig); hipFree(c.idx.tbox); hipFree(c.idx.sbox); hipFree(c.keys); hipFree(c.bb);
-  hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn); hipFree(c.part_d); hipFree(c.part_i);
+  hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.p4); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn); hipFree(c.part_d); hipFree(c.part_i); hipFree(c.redo); hipFree(c.kth);
   c = DevCloud();
 }
 
 int ensure_cloud(gorio_apd* h, DevCloud& c, int n) {
   const int n_pad = roundup(n, kPad) + kPad;
   if (n_pad > c.cap) {
-    hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn);
-    c.x = c.y = c.z = c.label = nullptr; c.cov6 = c.geo_w = nullptr; c.knn = nullptr; c.knn_k = 0;
+    hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.p4); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn);
+    c.x = c.y = c.z = c.label = nullptr; c.p4 = nullptr; c.cov6 = c.geo_w = nullptr; c.knn = nullptr; c.knn_k = 0;
     const int cap = n_pad + n_pad / 8;
     HIP_TRY(h, hipMalloc(&c.x, sizeof(float) * cap));
     HIP_TRY(h, hipMalloc(&c.y, sizeof(float) * cap));
     HIP_TRY(h, hipMalloc(&c.z, sizeof(float) * cap));
     HIP_TRY(h, hipMalloc(&c.label, sizeof(float) * cap));
+    HIP_TRY(h, hipMalloc(&c.p4, sizeof(float4) * cap));
     HIP_TRY(h, hipMalloc(&c.cov6, sizeof(double) * 6 * cap));
     HIP_TRY(h, hipMalloc(&c.geo_w, sizeof(double) * cap));
     c.cap = cap;
@@ -158,8 +164,8 @@ int upload_cloud(gorio_apd* h, DevCloud& c, const float* xyz, const float* label
   int rc = ensure_cloud(h, c, n);
   if (rc) return rc;
   const int np = c.n_pad;
-  std::vector<float> buf((size_t)np * 4);
-  float *bx = buf.data(), *by = bx + np, *bz = by + np, *bl = bz + np;
+  std::vector<float> buf((size_t)np * 8);
+  float *bx = buf.data(), *by = bx + np, *bz = by + np, *bl = bz + np, *b4 = bl + np;
   const int st = stride_bytes / 4;
   for (int i = 0; i < n; ++i) {
     const float* p = xyz + (size_t)i * st;
@@ -167,10 +173,12 @@ int upload_cloud(gorio_apd* h, DevCloud& c, const float* xyz, const float* label
     bl[i] = label ? label[(size_t)i * st] : 0.0f;
   }
   for (int i = n; i < np; ++i) { bx[i] = kFar; by[i] = kFar; bz[i] = kFar; bl[i] = 0.0f; }
+  for (int i = 0; i < np; ++i) { b4[4 * (size_t)i] = bx[i]; b4[4 * (size_t)i + 1] = by[i]; b4[4 * (size_t)i + 2] = bz[i]; b4[4 * (size_t)i + 3] = bl[i]; }
   HIP_TRY(h, hipMemcpyAsync(c.x, bx, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(c.y, by, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(c.z, bz, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(c.label, bl, sizeof(float) * np, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(c.p4, b4, sizeof(float4) * np, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   c.present = true;
   c.cov_count = 0;
@@ -180,20 +188,16 @@ int upload_cloud(gorio_apd* h, DevCloud& c, const float* xyz, const float* label
 
 // setInput* from device-resident SoA buffers: one launch copies the four arrays and writes the padding
 __global__ __launch_bounds__(256) void copy_cloud_kernel(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz, const float* __restrict__ sl,
-                                                         float* __restrict__ x, float* __restrict__ y, float* __restrict__ z, float* __restrict__ label, int n, int n_pad) {
+                                                         float* __restrict__ x, float* __restrict__ y, float* __restrict__ z, float* __restrict__ label, float4* __restrict__ p4, int n, int n_pad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_pad) return;
-  if (i < n) {
-    x[i] = sx[i];
-    y[i] = sy[i];
-    z[i] = sz[i];
-    label[i] = sl ? sl[i] : 0.0f;
-  } else {
-    x[i] = 1e30f;
-    y[i] = 1e30f;
-    z[i] = 1e30f;
-    label[i] = 0.0f;
-  }
+  const bool in = i < n;
+  const float4 v = make_float4(in ? sx[i] : 1e30f, in ? sy[i] : 1e30f, in ? sz[i] : 1e30f, (in && sl) ? sl[i] : 0.0f);
+  x[i] = v.x;
+  y[i] = v.y;
+  z[i] = v.z;
+  label[i] = v.w;
+  p4[i] = v;
 }
 
 int upload_cloud_device(gorio_apd* h, DevCloud& c, const float* dx, const float* dy, const float* dz, const float* dl, int n) {
@@ -201,7 +205,7 @@ int upload_cloud_device(gorio_apd* h, DevCloud& c, const float* dx, const float*
   HIP_TRY(h, hipSetDevice(h->device));
   int rc = ensure_cloud(h, c, n);
   if (rc) return rc;
-  copy_cloud_kernel<<<(c.n_pad + 255) / 256, 256, 0, h->stream>>>(dx, dy, dz, dl, c.x, c.y, c.z, c.label, n, c.n_pad);
+  copy_cloud_kernel<<<(c.n_pad + 255) / 256, 256, 0, h->stream>>>(dx, dy, dz, dl, c.x, c.y, c.z, c.label, c.p4, n, c.n_pad);
   HIP_TRY(h, hipGetLastError());
   c.present = true;
   c.cov_count = 0;
@@ -214,16 +218,19 @@ int upload_cloud_device(gorio_apd* h, DevCloud& c, const float* dx, const float*
 struct CopyJob {
   const float* sx; const float* sy; const float* sz; const float* sl;
   float* x; float* y; float* z; float* label;
+  float4* p4;
   int n, n_pad;
 };
 __global__ __launch_bounds__(256) void copy_clouds_kernel(const CopyJob* __restrict__ jobs) {
   const CopyJob jb = jobs[blockIdx.y];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.n_pad; i += gridDim.x * 256) {
     const bool in = i < jb.n;
-    jb.x[i] = in ? jb.sx[i] : 1e30f;
-    jb.y[i] = in ? jb.sy[i] : 1e30f;
-    jb.z[i] = in ? jb.sz[i] : 1e30f;
-    jb.label[i] = (in && jb.sl) ? jb.sl[i] : 0.0f;
+    const float4 v = make_float4(in ? jb.sx[i] : 1e30f, in ? jb.sy[i] : 1e30f, in ? jb.sz[i] : 1e30f, (in && jb.sl) ? jb.sl[i] : 0.0f);
+    jb.x[i] = v.x;
+    jb.y[i] = v.y;
+    jb.z[i] = v.z;
+    jb.label[i] = v.w;
+    jb.p4[i] = v;
   }
 }
 
@@ -335,7 +342,7 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
   HIP_TRY(lead, hipMemcpyAsync(lead->d_ijobs, jobs.data(), sizeof(IndexJob) * nj, hipMemcpyHostToDevice, lead->stream));
   HIP_TRY(lead, hipStreamSynchronize(lead->stream));  // pageable staging
   {
-    StageTimer t(lead, 0);
+    StageTimer t(lead, 4);
     const IndexJob* dj = lead->d_ijobs;
     bbox_init_kernel<<<(nj + 63) / 64, 64, 0, lead->stream>>>(dj, nj);
     bbox_kernel<<<dim3(std::min(64, (max_n + 255) / 256), nj), 256, 0, lead->stream>>>(dj);
@@ -362,6 +369,7 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
   const int k = lead->params.k_correspondences;
   const int K = k <= 20 ? 20 : 32;
   const bool pruned = lead->params.search == GORIO_SEARCH_PRUNED;
+  const bool select = pruned && K == 20;  // knn_kth_kernel + knn_collect_kernel (LDS buffer sized for K = 20); K = 32 keeps the insertion kernel
   if (pruned) {
     int rc = run_index_build(lead, todo);
     if (rc) return rc;
@@ -393,17 +401,31 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
       HIP_TRY(h, hipMalloc(&c.part_i, sizeof(int) * need));
       c.part_cap = need;
     }
-    if (c.knn_k != k || !c.knn) {
+    const bool keep = h->params.keep_knn_indices != 0;
+    if (keep && (c.knn_k != k || !c.knn)) {
       hipFree(c.knn);
       c.knn = nullptr;
       HIP_TRY(h, hipMalloc(&c.knn, sizeof(int) * (size_t)c.cap * k));
       c.knn_k = k;
     }
+    c.knn_valid = keep;
+    if (select) {
+      const int nw = roundup(c.n, 512) / 64;
+      if (nw > c.redo_cap) {
+        hipFree(c.redo); hipFree(c.kth);
+        c.redo = nullptr; c.kth = nullptr;
+        HIP_TRY(h, hipMalloc(&c.redo, sizeof(int) * (nw + nw / 8)));
+        HIP_TRY(h, hipMalloc(&c.kth, sizeof(float) * 64 * (nw + nw / 8)));
+        c.redo_cap = nw + nw / 8;
+      }
+    }
     KnnJob& j = jobs[q];
     j.cloud = c.view();
     j.part_d = c.part_d;
     j.part_i = c.part_i;
-    j.knn_out = c.knn;
+    j.knn_out = keep ? c.knn : nullptr;
+    j.redo = select ? c.redo : nullptr;
+    j.kth = select ? c.kth : nullptr;
     j.k = k;
     j.regularization = h->params.regularization;
     j.splits = s;
@@ -422,8 +444,11 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     dim3 g1((max_n + 255) / 256, max_splits, njobs), g2((max_n + 255) / 256, 1, njobs);
     dim3 gp((roundup(max_n, 512) + 255) / 256, 1, njobs);
     if (K == 20) {
-      if (pruned) knn_pruned_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
-      else {
+      if (pruned) {
+        knn_kth_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
+        knn_collect_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
+        knn_pruned_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);  // only the waves knn_collect_kernel flagged (massive ties) do anything
+      } else {
         knn_partial_kernel<20><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
         cov_finalize_kernel<20><<<g2, 256, 0, lead->stream>>>(lead->d_jobs);
       }
@@ -669,6 +694,7 @@ void gorio_apd_default_params(gorio_apd_params* p) {
   p->lm_init_lambda_factor = 1e-9;
   p->search = GORIO_SEARCH_BRUTE_FORCE;
   p->cl_weight_points = 0;
+  p->keep_knn_indices = 0;
 }
 
 int gorio_apd_create(gorio_apd_t** out, int device) {
@@ -765,7 +791,7 @@ int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const go
         if (h != lead) lead->err = h->err;
         return rc;
       }
-      jobs.push_back(CopyJob{in.x, in.y, in.z, in.label, c.x, c.y, c.z, c.label, in.n, c.n_pad});
+      jobs.push_back(CopyJob{in.x, in.y, in.z, in.label, c.x, c.y, c.z, c.label, c.p4, in.n, c.n_pad});
       max_pad = std::max(max_pad, c.n_pad);
       c.present = true;
       c.cov_count = 0;
@@ -806,8 +832,14 @@ int gorio_apd_swap_source_and_target(gorio_apd_t* h) {
 }
 
 static int set_covs(gorio_apd* h, DevCloud& c, const double* cov, int n) {
-  if (!cov || n <= 0) return fail(h, GORIO_ERR_INVALID, "set_covariances: bad arguments");
-  if (!c.present || n != c.n) return fail(h, GORIO_ERR_STATE, "set_covariances: size does not match the cloud (the reference would recompute them, APD:149-154)");
+  if (n < 0 || (n > 0 && !cov)) return fail(h, GORIO_ERR_INVALID, "set_covariances: bad arguments");
+  if (!c.present || n != c.n) {
+    // the reference stores the vector whatever its size (APD:138-145) and recomputes the covariances in computeTransformation when the
+    // size does not match the cloud (APD:149-154): a mismatching set is therefore the same as none
+    c.cov_count = 0;
+    c.knn_valid = false;
+    return GORIO_OK;
+  }
   HIP_TRY(h, hipSetDevice(h->device));
   std::vector<double> c6((size_t)n * 6);
   for (int i = 0; i < n; ++i) {
@@ -820,6 +852,7 @@ static int set_covs(gorio_apd* h, DevCloud& c, const double* cov, int n) {
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   c.cov_count = n;
+  c.knn_valid = false;  // these covariances did not come from a k-NN search of this library
   return GORIO_OK;
 }
 
@@ -868,7 +901,7 @@ int gorio_apd_calculate_covariances(gorio_apd_t* h) {
 int gorio_apd_get_knn_indices(gorio_apd_t* h, int which, int* idx, int n_times_k) {
   if (!h || !idx) return GORIO_ERR_INVALID;
   DevCloud& c = which == 0 ? h->src : h->tgt;
-  if (!c.present || !c.knn || c.cov_count != c.n) return fail(h, GORIO_ERR_STATE, "no k-NN result held for this cloud");
+  if (!c.present || !c.knn || !c.knn_valid || c.cov_count != c.n) return fail(h, GORIO_ERR_STATE, "no k-NN result held for this cloud (set params.keep_knn_indices before the covariances are computed)");
   if (n_times_k != c.n * c.knn_k) return fail(h, GORIO_ERR_INVALID, "get_knn_indices: size mismatch");
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipMemcpyAsync(idx, c.knn, sizeof(int) * (size_t)n_times_k, hipMemcpyDeviceToHost, h->stream));
@@ -1063,13 +1096,13 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
 int gorio_apd_set_profiling(gorio_apd_t* h, int enable) {
   if (!h) return GORIO_ERR_INVALID;
   h->profiling = enable != 0;
-  for (int i = 0; i < 4; ++i) { h->stage_s[i] = 0; h->stage_n[i] = 0; }
+  for (int i = 0; i < 8; ++i) { h->stage_s[i] = 0; h->stage_n[i] = 0; }
   return GORIO_OK;
 }
 
-int gorio_apd_get_stage_times(gorio_apd_t* h, double seconds[4], int counts[4]) {
+int gorio_apd_get_stage_times(gorio_apd_t* h, double seconds[8], int counts[8]) {
   if (!h) return GORIO_ERR_INVALID;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     if (seconds) seconds[i] = h->stage_s[i];
     if (counts) counts[i] = h->stage_n[i];
   }

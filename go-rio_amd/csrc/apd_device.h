@@ -3,6 +3,7 @@
 // HBM layout of one cloud (FastAPDGICP::input_ / target_ + source_covs_ / target_covs_, APDH:109-110):
 //   x[n_pad], y[n_pad], z[n_pad], label[n_pad]  float SoA; n_pad = n rounded up to 16 (+16), padding coordinates = 1e30 so a
 //                                                padded candidate has distance +inf and can never win a search
+//   p4[n_pad]    float4 (x, y, z, label): the gather copy (the SoA arrays feed the wave-uniform / coalesced streams)
 //   cov6[n][6]   double, upper triangle (c00 c01 c02 c11 c12 c22) of the 3x3 block of the 4x4 covariance (row/col 3 are 0)
 //   geo_w[n]     double, sigma3/sigma1 of the regularised covariance (APD:266-269; a pure function of cov6)
 // Per source point of a pair (FastAPDGICP::correspondences_, sq_distances_, mahalanobis_, APDH:111-114):
@@ -35,6 +36,7 @@ struct CloudView {
   float* y;
   float* z;
   float* label;
+  float4* p4;       // [n_pad] the same points once more as (x, y, z, label): ONE 16-byte access where a kernel gathers a point by index
   double* cov6;
   double* geo_w;
   int n;
@@ -85,7 +87,10 @@ struct KnnJob {
   CloudView cloud;
   float* part_d;  // [splits][K][n]
   int* part_i;
-  int* knn_out;   // [n][k] or null
+  int* knn_out;   // [n][k] or null (parity hook: only kept when gorio_apd_params.keep_knn_indices is set)
+  int* redo;      // [ceil(n_spad / 64)] per query wave: 1 = knn_collect_kernel gave up (more ties than its buffer holds), the
+                  // insertion kernel knn_pruned_kernel redoes that wave; null = knn_pruned_kernel does every wave
+  float* kth;     // [n_spad] k-th smallest distance of every query by SORTED position (knn_kth_kernel -> knn_collect_kernel)
   int k;
   int regularization;
   int splits;

@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   if (st->n_linearize > 0 && p < si.n) {
     const int pc = pd.corr[si.orig[pq]];
     if (pc >= 0 && pc < pd.tgt.n) {
-      const float d = sqdist3(qx, qy, qz, pd.tgt.x[pc], pd.tgt.y[pc], pd.tgt.z[pc]);
+      const float4 tp = pd.tgt.p4[pc];
+      const float d = sqdist3(qx, qy, qz, tp.x, tp.y, tp.z);
       const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)pc;
       if (key < best) {
         best = key;
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= n) return;
   const int lane = threadIdx.x & 63;
+  if (job.redo && job.redo[(blockIdx.x * 256 + threadIdx.x) >> 6] == 0) return;  // this wave was done by knn_select_kernel
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
   const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
@@ -670,6 +672,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
     covariance_from_list<K>(job, si.orig[p], bd, bi);
   }  // lists never leave the registers: no partial lists, no second kernel
+}
+
+// ----------------------------------------------------------------------------------------------- self k-NN by SELECTION
+//
+// knn_pruned_kernel above keeps a sorted (distance, index) list per lane and pays a 20-slot 64-bit insertion (~105 VALU instructions)
+// for every candidate ANY lane of the wave accepts, tile by tile: it runs at a quarter of the VALU issue rate (divergent rounds,
+// LDS round trips) and 78 % of what it does issue is insertion.  The two kernels below find the same lists by selection:
+//   knn_kth_kernel      the k-th smallest DISTANCE of every query, exactly: a sorted list of K floats per lane; a candidate c of a needed
+//                       tile is inserted from the back, slot t becoming med3(D[t-1], c, D[t]) of the OLD neighbours: one instruction per
+//                       slot, no carry chain, no compare, no divergence, no LDS; candidates no lane can use are skipped for the whole
+//                       wave.  The multiset of the K smallest distances does not need the indices.  (v_med3 / v_min / v_max / v_cmp /
+//                       v_cndmask all issue at HALF rate on gfx950 -- tools/valu_rate.hip -- so a 64-bit (distance, index) insertion
+//                       costs 5 half-rate instructions per slot where this costs one.)
+//   knn_collect_kernel  walks the tiles again with the now exact bound d_k; every candidate with d <= d_k (at most K - 1 below d_k plus
+//                       the ties at d_k) is appended to a lane-private LDS column as a packed (distance, original index) key; the
+//                       <= CAP buffered keys are then sorted into the register list with the 64-bit insertion (dense: every lane has
+//                       ~K of them), which also resolves ties on the original index, and the covariance is formed from the list
+//                       (covariance_from_list) as before.
+// A wave in which some lane meets more than CAP candidates at or below its d_k (only with many exactly equal distances: lattices,
+// duplicated points) flags itself in job.redo and is redone by knn_pruned_kernel, so the result is exact for every input.
+// grid of both: (ceil(n_spad / 256), 1, clouds), block 256.
+
+template <int K>
+__global__ __launch_bounds__(256) void knn_kth_kernel(const KnnJob* __restrict__ jobs) {
+  const KnnJob& job = jobs[blockIdx.z];
+  const SearchIndex& si = job.cloud.idx;
+  const int n = si.n;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int pq = p < n ? p : n - 1;
+  const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
+  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
+  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
+  const scalar_fp tx = as_scalar(si.sx);
+  const scalar_fp ty = as_scalar(si.sy);
+  const scalar_fp tz = as_scalar(si.sz);
+  const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
+  const int ng = (si.n_tiles + 63) / 64;
+  const int own_tile = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + (threadIdx.x & ~63)) / 32);
+  const int g0 = own_tile / 64;
+  float D[K];  // the K smallest distances met so far, ascending
+#pragma unroll
+  for (int t = 0; t < K; ++t) D[t] = INFINITY;
+  for (int v = 0; v < 2 * ng; ++v) {
+    const int off = (v + 1) >> 1;
+    const int g = (v & 1) ? g0 - off : g0 + off;
+    if (g < 0 || g >= ng) continue;
+    const int tl = g * 64 + lane;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    if (tl < si.n_tiles) {
+      lo = tb4[2 * (size_t)tl];
+      hi = tb4[2 * (size_t)tl + 1];
+    }
+    for (int phase = (g == g0 ? 0 : 1); phase < 2; ++phase) {  // own tiles first: they fill the list with near neighbours
+      const float wb = wave_max(D[K - 1]);
+      unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) < wb);  // strictly below: an equal distance changes no distance list
+      if (g == g0) {
+        const int ol = own_tile - g * 64;
+        const unsigned long long near = (((ol + 3) >= 64) ? ~0ull : ((1ull << (ol + 3)) - 1ull)) & ~((ol >= 1) ? ((1ull << (ol - 1)) - 1ull) : 0ull);  // tiles ol-1 .. ol+2
+        mask = phase == 0 ? (mask & near) : (mask & ~near);
+      }
+      while (mask) {
+        const int tlane = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+        if (__ballot(box_bound(qx, qy, qz, bx) < D[K - 1]) == 0) continue;
+        const int j0 = (g * 64 + tlane) * 32;
+#pragma unroll 2
+        for (int gg = 0; gg < 32; gg += 8) {
+          float d[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + gg + u], ty[j0 + gg + u], tz[j0 + gg + u]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float c = d[u];
+            if (__ballot(c < D[K - 1]) == 0) continue;  // no lane's list changes: skip the insertion for the whole wave
+            // insertion from the back: the new slot t is the median of (old D[t-1], c, old D[t]) -- every slot from OLD values, so the
+            // K operations are independent (no carry chain); descending t keeps D[t-1] old when slot t is written
+#pragma unroll
+            for (int t = K - 1; t > 0; --t) D[t] = __builtin_amdgcn_fmed3f(D[t - 1], c, D[t]);
+            D[0] = __builtin_amdgcn_fmed3f(D[0], c, -INFINITY);  // min(D[0], c) without the canonicalisation fminf would add
+          }
+        }
+      }
+    }
+  }
+  job.kth[p] = D[K - 1];  // indexed by SORTED position (n_spad entries)
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void knn_collect_kernel(const KnnJob* __restrict__ jobs) {
+  const KnnJob& job = jobs[blockIdx.z];
+  const SearchIndex& si = job.cloud.idx;
+  const int n = si.n;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int pq = p < n ? p : n - 1;
+  const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
+  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
+  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
+  const scalar_fp tx = as_scalar(si.sx);
+  const scalar_fp ty = as_scalar(si.sy);
+  const scalar_fp tz = as_scalar(si.sz);
+  const scalar_ip to = (scalar_ip)si.orig;
+  const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
+  constexpr int CAP = K + 4;
+  __shared__ unsigned long long s_buf[CAP][256];  // keys at or below d_k, one column per lane (bank = lane: conflict free)
+  const int ng = (si.n_tiles + 63) / 64;
+  const float dk = job.kth[p];
+  int cnt = 0;
+  {
+    const float wb = wave_max(dk);
+    for (int g = 0; g < ng; ++g) {
+      const int tl = g * 64 + lane;
+      float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+      if (tl < si.n_tiles) {
+        lo = tb4[2 * (size_t)tl];
+        hi = tb4[2 * (size_t)tl + 1];
+      }
+      unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= wb);
+      while (mask) {
+        const int tlane = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+        if (__ballot(box_bound(qx, qy, qz, bx) <= dk) == 0) continue;
+        const int j0 = (g * 64 + tlane) * 32;
+#pragma unroll
+        for (int gg = 0; gg < 32; gg += 8) {
+          float d[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + gg + u], ty[j0 + gg + u], tz[j0 + gg + u]);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (d[u] <= dk) {
+              if (cnt < CAP) s_buf[cnt][threadIdx.x] = ((unsigned long long)__float_as_uint(d[u]) << 32) | (unsigned int)to[j0 + gg + u];
+              ++cnt;
+            }
+          }
+        }
+      }
+    }
+  }
+  const bool redo = __ballot(cnt > CAP) != 0ull;
+  if (lane == 0) job.redo[(blockIdx.x * 256 + threadIdx.x) >> 6] = redo ? 1 : 0;
+  if (redo) return;
+  // sort the buffered keys (ties fall to the lower original index, surplus ties beyond K drop off the end)
+  unsigned long long L[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) L[t] = 0x7f8000007fffffffull;  // (+inf, int max)
+  int rounds = cnt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o, 64));
+  for (int r = 0; r < rounds; ++r) {
+    if (r < cnt) topk_insert_key<K>(L, s_buf[r][threadIdx.x]);
+  }
+  if (p < n) {
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      bd[t] = __uint_as_float((unsigned int)(L[t] >> 32));
+      bi[t] = (int)(unsigned int)(L[t] & 0xffffffffull);
+    }
+    covariance_from_list<K>(job, si.orig[p], bd, bi);
+  }
 }
 
 }  // namespace gorio

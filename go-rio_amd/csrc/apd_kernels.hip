@@ -234,17 +234,22 @@ __device__ __forceinline__ void covariance_from_list(const KnnJob& job, int i, c
     for (int t = 0; t < K; ++t)
       if (t < k) job.knn_out[(size_t)i * k + t] = bi[t];
   }
-  const float* __restrict__ cx = job.cloud.x;
-  const float* __restrict__ cy = job.cloud.y;
-  const float* __restrict__ cz = job.cloud.z;
-  // APD:366-372 in the neighbour order of the list (same order as the oracle => bit-identical sums)
+  // APD:366-372 in the neighbour order of the list (same order as the oracle => bit-identical sums).  The k neighbours are gathered
+  // ONCE, one 16-byte access each from the (x, y, z, label) copy of the cloud, and kept in registers for both passes.
+  const float4* __restrict__ pts = job.cloud.p4;
+  float px[K], py[K], pz[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    const float4 v = pts[t < k ? bi[t] : bi[0]];
+    px[t] = v.x; py[t] = v.y; pz[t] = v.z;
+  }
   double mx = 0.0, my = 0.0, mz = 0.0;
 #pragma unroll
   for (int t = 0; t < K; ++t)
     if (t < k) {
-      mx += (double)cx[bi[t]];
-      my += (double)cy[bi[t]];
-      mz += (double)cz[bi[t]];
+      mx += (double)px[t];
+      my += (double)py[t];
+      mz += (double)pz[t];
     }
   const double kd = (double)k;
   mx /= kd;
@@ -254,7 +259,7 @@ __device__ __forceinline__ void covariance_from_list(const KnnJob& job, int i, c
 #pragma unroll
   for (int t = 0; t < K; ++t)
     if (t < k) {
-      const double dx = (double)cx[bi[t]] - mx, dy = (double)cy[bi[t]] - my, dz = (double)cz[bi[t]] - mz;
+      const double dx = (double)px[t] - mx, dy = (double)py[t] - my, dz = (double)pz[t] - mz;
       c00 += dx * dx;
       c01 += dx * dy;
       c02 += dx * dz;
@@ -265,6 +270,8 @@ __device__ __forceinline__ void covariance_from_list(const KnnJob& job, int i, c
   c00 /= kd; c01 /= kd; c02 /= kd; c11 /= kd; c12 /= kd; c22 /= kd;
 
   double r00, r01, r02, r11, r12, r22;
+  double geo = 0.0;
+  bool have_geo = false;
   if (job.regularization == 0) {  // NONE, APD:374-376
     r00 = c00; r01 = c01; r02 = c02; r11 = c11; r12 = c12; r22 = c22;
   } else if (job.regularization == 4) {  // FROBENIUS, APD:377-383: (C_inv / ||C_inv||_F)^-1 with C = cov + 1e-3 I
@@ -290,10 +297,15 @@ __device__ __forceinline__ void covariance_from_list(const KnnJob& job, int i, c
     r11 = e.v10 * l0 * e.v10 + e.v11 * l1 * e.v11 + e.v12 * l2 * e.v12;
     r12 = e.v10 * l0 * e.v20 + e.v11 * l1 * e.v21 + e.v12 * l2 * e.v22;
     r22 = e.v20 * l0 * e.v20 + e.v21 * l1 * e.v21 + e.v22 * l2 * e.v22;
+    // APD:266-269 take sigma_3 / sigma_1 of THIS matrix; it was just assembled as V diag(l) V^T with orthonormal V, so its singular
+    // values are l0, l1, l2 (to rounding: the second decomposition the reference runs per point per call can differ by ~1e-16 relative,
+    // in a weight that only scales the LM acceptance error)
+    geo = fmin(l0, fmin(l1, l2)) / fmax(l0, fmax(l1, l2));
+    have_geo = true;
   }
   double* o = job.cloud.cov6 + (size_t)i * 6;
   o[0] = r00; o[1] = r01; o[2] = r02; o[3] = r11; o[4] = r12; o[5] = r22;
-  job.cloud.geo_w[i] = geo_weight(r00, r01, r02, r11, r12, r22);
+  job.cloud.geo_w[i] = have_geo ? geo : geo_weight(r00, r01, r02, r11, r12, r22);
 }
 
 // grid: (ceil(n/256), 1, clouds).  Merges the per-split lists, then APD:366-407 per point.
@@ -470,8 +482,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         om[0] = p.o00; om[1] = p.o01; om[2] = p.o02; om[3] = p.o11; om[4] = p.o12; om[5] = p.o22;
       }
 
-      const double quad = residual_terms(T, ax, ay, az, pd.tgt.x[j], pd.tgt.y[j], pd.tgt.z[j], p);  // APD:255-263
-      const double w = 1.0 + pd.src.geo_w[i] + ((pd.tgt.label[j] == pd.src.label[i]) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);  // APD:266-276
+      const float4 tb = pd.tgt.p4[j];  // the matched target point and its cluster label in one 16-byte gather
+      const double quad = residual_terms(T, ax, ay, az, tb.x, tb.y, tb.z, p);  // APD:255-263
+      const double w = 1.0 + pd.src.geo_w[i] + ((tb.w == pd.src.label[i]) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);  // APD:266-276
       acc[27] = w * quad;
 
       // J = [skew(Ta) | -I], APD:284-287.  With S = skew(Ta): H_rr = S^T O S, H_rt = -S^T O, H_tt = O, b_r = S^T O e, b_t = -O e.
@@ -628,8 +641,9 @@ __device__ double block_error(const PairDesc& pd, const double* __restrict__ T, 
     const double* om = pd.omega6 + (size_t)i * 6;
     PointTerms p;
     p.o00 = om[0]; p.o01 = om[1]; p.o02 = om[2]; p.o11 = om[3]; p.o12 = om[4]; p.o22 = om[5];
-    const double quad = residual_terms(T, pd.src.x[i], pd.src.y[i], pd.src.z[i], pd.tgt.x[j], pd.tgt.y[j], pd.tgt.z[j], p);
-    const double w = 1.0 + pd.src.geo_w[i] + ((pd.tgt.label[j] == pd.src.label[i]) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);
+    const float4 tb = pd.tgt.p4[j];
+    const double quad = residual_terms(T, pd.src.x[i], pd.src.y[i], pd.src.z[i], tb.x, tb.y, tb.z, p);
+    const double w = 1.0 + pd.src.geo_w[i] + ((tb.w == pd.src.label[i]) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);
     sum += w * quad;
   }
   sum = wave_sum(sum);

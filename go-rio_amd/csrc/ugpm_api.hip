@@ -24,8 +24,8 @@ namespace {
 constexpr int kEvalSplit = 6;  // workgroups per window in the residual / Jacobian evaluators
 
 thread_local std::string g_err;
-thread_local double g_stage_s[5] = {0, 0, 0, 0, 0};
-thread_local int g_stage_n[5] = {0, 0, 0, 0, 0};
+thread_local double g_stage_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local int g_stage_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 struct Ctx {  // per-thread, per-device cached buffers
   int device = -1;
@@ -118,21 +118,24 @@ size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* b
   return ((size_t)(p - base) + 31) / 32 * 32;
 }
 
-struct Stage {
+struct Stage {  // HIP events around a group of launches on `stream` (default: the context's main stream); may nest
   Ctx& c;
+  hipStream_t stream;
+  size_t slot = 0;
   bool on;
-  Stage(Ctx& c_, int s) : c(c_), on(true) {
+  Stage(Ctx& c_, int s, hipStream_t st = nullptr) : c(c_), stream(st ? st : c_.stream), on(true) {
     hipEvent_t a = nullptr, b = nullptr;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
       on = false;
       return;
     }
+    slot = c.ev.size();
     c.ev.emplace_back(a, b);
     c.ev_stage.push_back(s);
-    hipEventRecord(a, c.stream);
+    hipEventRecord(a, stream);
   }
   ~Stage() {
-    if (on) hipEventRecord(c.ev.back().second, c.stream);
+    if (on) hipEventRecord(c.ev[slot].second, stream);
   }
 };
 
@@ -213,8 +216,8 @@ void gorio_ugpm_default_window(gorio_ugpm_window* w) {
 
 const char* gorio_ugpm_last_error(void) { return g_err.c_str(); }
 
-int gorio_ugpm_get_stage_times(double seconds[5], int counts[5]) {
-  for (int i = 0; i < 5; ++i) {
+int gorio_ugpm_get_stage_times(double seconds[8], int counts[8]) {
+  for (int i = 0; i < 8; ++i) {
     if (seconds) seconds[i] = g_stage_s[i];
     if (counts) counts[i] = g_stage_n[i];
   }
@@ -249,7 +252,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       for (const void* f : fns) UHIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     }
   }
-  for (int i = 0; i < 5; ++i) { g_stage_s[i] = 0; g_stage_n[i] = 0; }
+  for (int i = 0; i < 8; ++i) { g_stage_s[i] = 0; g_stage_n[i] = 0; }
   const bool trace = std::getenv("GORIO_UGPM_TRACE") != nullptr;
   auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tt0 = tnow();
@@ -499,6 +502,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   if (max_S > 0) {
     // J^T J launches: one workgroup per (row slice, tile group, window), see ata_kernel
     auto launch_ata = [&](int which) {
+      Stage st_ata(c, which == 2 ? 6 : 5);
       const int n = (which == 2 ? 6 : 3) * max_S, T = (n + 15) / 16, ntile = T * (T + 1) / 2;
       const int tpg = which == 2 ? kAtaTilesCorr : kAtaTilesLm;
       const int ng = (ntile + tpg - 1) / tpg;

@@ -120,15 +120,17 @@ public:
     target_covs_.clear();
     target_covs_fresh_ = false;
   }
+  // APD:138-145 store the vector whatever its size; APD:149-154 recompute at align when the size does not match the cloud.  The ABI
+  // call does the same: a mismatching set leaves the device without covariances for that cloud (no exception).
   virtual void setSourceCovariances(const CovarianceVector& covs) {  // APD:138-140
     source_covs_ = covs;
     source_covs_fresh_ = true;
-    check(gorio_apd_set_source_covariances(handle_, covs.empty() ? nullptr : covs[0].data(), static_cast<int>(covs.size())));
+    check(gorio_apd_set_source_covariances(handle_, covs.empty() ? nullptr : to_row_major_covs(covs).data(), static_cast<int>(covs.size())));
   }
   virtual void setTargetCovariances(const CovarianceVector& covs) {  // APD:143-145
     target_covs_ = covs;
     target_covs_fresh_ = true;
-    check(gorio_apd_set_target_covariances(handle_, covs.empty() ? nullptr : covs[0].data(), static_cast<int>(covs.size())));
+    check(gorio_apd_set_target_covariances(handle_, covs.empty() ? nullptr : to_row_major_covs(covs).data(), static_cast<int>(covs.size())));
   }
   const CovarianceVector& getSourceCovariances() const {  // APDH:73-75
     fetch_covs(true);
@@ -188,7 +190,7 @@ protected:
     // pcl::transformPointCloud(*input_, output, final_transformation_), LSQ:79 (xyz only, labels untouched)
     const int n = static_cast<int>(input_->size());
     if (static_cast<int>(output.size()) != n) output.points = input_->points;
-    check(gorio_apd_transform_source(handle_, T, output.points[0].data, n, sizeof(PointSource)));
+    if (n > 0) check(gorio_apd_transform_source(handle_, T, output.points[0].data, n, sizeof(PointSource)));
   }
 
   virtual void update_correspondences(const Eigen::Isometry3d& trans) { linearize(trans, nullptr, nullptr); }  // APD:160-220
@@ -220,12 +222,22 @@ private:
     for (int r = 0; r < 4; ++r)
       for (int c = 0; c < 4; ++c) out[r * 4 + c] = static_cast<S>(m(r, c));
   }
+  static std::vector<double> to_row_major_covs(const CovarianceVector& covs) {  // Eigen::Matrix4d is column-major, the ABI row-major
+    std::vector<double> rm(covs.size() * 16);
+    for (std::size_t i = 0; i < covs.size(); ++i)
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) rm[i * 16 + r * 4 + c] = covs[i](r, c);
+    return rm;
+  }
   void check(int rc) const {
     if (rc < 0) throw std::runtime_error(std::string("FastAPDGICP (gorio_amd): ") + gorio_apd_last_error(handle_) + " [code " + std::to_string(rc) + "]");
   }
   template <typename P>
   void upload(const P* pts, int n, std::size_t stride, bool source) {
-    if (n <= 0) return;
+    if (n <= 0) {  // an empty cloud replaces the previous one: nothing must stay resident on the device for this side (align then fails)
+      check(source ? gorio_apd_clear_source(handle_) : gorio_apd_clear_target(handle_));
+      return;
+    }
     const float* xyz = pts[0].data;
     const float* label = &pts[0].normal_x;  // cluster label, APD:272
     check(source ? gorio_apd_set_source(handle_, xyz, label, n, static_cast<int>(stride)) : gorio_apd_set_target(handle_, xyz, label, n, static_cast<int>(stride)));

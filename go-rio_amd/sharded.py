@@ -43,6 +43,49 @@ def so3_exp_matrix(omega):
     return np.array([[1 - (tyy + tzz), txy - twz, txz + twy], [txy + twz, 1 - (txx + tzz), tyz - twx], [txz - twy, tyz + twx, 1 - (txx + tyy)]])
 
 
+def ldlt6_solve(A, rhs):
+    """Eigen::LDLT<Matrix6d>(A).solve(rhs) as LsqRegistration uses it (lsq_registration_impl.hpp:112, 137): L D L^T with symmetric
+    diagonal pivoting, zero pivots skipped (a singular H -- e.g. no correspondence at all -- gives a zero step, not an exception).
+    The same operation order as ldlt6_solve in go-rio_amd/csrc/apd_kernels.hip, so a sharded run and a single-handle run take
+    identical steps from identical H, b."""
+    A = np.array(A, dtype=np.float64)
+    n = A.shape[0]
+    perm = list(range(n))
+    for k in range(n):
+        piv = k + int(np.argmax(np.abs(np.diag(A)[k:])))
+        if abs(A[piv, piv]) <= abs(A[k, k]):
+            piv = k  # first maximum, like the strict '>' scan of the kernel
+        if piv != k:
+            A[[k, piv], :] = A[[piv, k], :]
+            A[:, [k, piv]] = A[:, [piv, k]]
+            perm[k], perm[piv] = perm[piv], perm[k]
+        d = A[k, k]
+        if d == 0.0:
+            continue
+        col = A[:, k].copy()
+        for i in range(k + 1, n):
+            l = col[i] / d
+            for j in range(k + 1, i + 1):
+                A[i, j] -= l * col[j]
+            A[i, k] = l
+        for i in range(k + 1, n):
+            for j in range(i + 1, n):
+                A[i, j] = A[j, i]
+    y = np.array([rhs[perm[i]] for i in range(n)], dtype=np.float64)
+    for i in range(n):
+        for j in range(i):
+            y[i] -= A[i, j] * y[j]
+    for i in range(n):
+        y[i] = y[i] / A[i, i] if A[i, i] != 0.0 else 0.0
+    for i in range(n - 1, -1, -1):
+        for j in range(i + 1, n):
+            y[i] -= A[j, i] * y[j]
+    x = np.zeros(n)
+    for i in range(n):
+        x[perm[i]] = y[i]
+    return x
+
+
 def _delta(d):
     D = np.eye(4)
     D[:3, :3] = so3_exp_matrix(d[:3])  # rotation block first (lsq_registration_impl.hpp:117-119, 140-142)
@@ -70,7 +113,7 @@ def align_sharded(reg, guess=None, max_iterations=64, rotation_epsilon=2e-3, tra
         n_lin += 1
         ok = False
         if optimizer == "GN":  # lsq_registration_impl.hpp:107-123
-            delta = _delta(np.linalg.solve(H, -b))
+            delta = _delta(ldlt6_solve(H, -b))
             x0 = delta @ x0
             Hfin, ok = H, True
         else:  # lsq_registration_impl.hpp:127-173
@@ -78,7 +121,7 @@ def align_sharded(reg, guess=None, max_iterations=64, rotation_epsilon=2e-3, tra
                 lam = lm_init_lambda_factor * np.abs(np.diag(H)).max()
             nu = 2.0
             for _ in range(lm_max_iterations):
-                d = np.linalg.solve(H + lam * np.eye(6), -b)
+                d = ldlt6_solve(H + lam * np.eye(6), -b)
                 delta = _delta(d)
                 xi = delta @ x0
                 yi = float(_all_reduce_sum(np.array([reg.compute_error(xi)]), group, device)[0])

@@ -127,8 +127,8 @@ def ugpm_preint_batch(windows, device=0, infer_t=None, type=UGPM, state_freq=50.
 
 def ugpm_stage_times():
     lib = load_library()
-    s = (C.c_double * 5)()
-    c = (C.c_int * 5)()
+    s = (C.c_double * 8)()
+    c = (C.c_int * 8)()
     lib.gorio_ugpm_get_stage_times(s, c)
     return list(s), list(c)
 

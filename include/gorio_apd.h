@@ -59,6 +59,8 @@ typedef struct {
   int search;                    /* gorio_search; default brute force */
   int cl_weight_points;          /* N in cl_weight = 1/N (APD:273: correspondences_.size()); 0 = this handle's source size.  Set it to
                                     the global source size when the source cloud is sharded over several handles / GPUs */
+  int keep_knn_indices;          /* parity hook: keep the k neighbour indices of every point for gorio_apd_get_knn_indices (80 B per point
+                                    of extra stores in the covariance kernel); default 0 */
 } gorio_apd_params;
 
 typedef struct gorio_apd gorio_apd_t;
@@ -104,7 +106,9 @@ int gorio_apd_clear_source(gorio_apd_t* h);
 int gorio_apd_clear_target(gorio_apd_t* h);
 int gorio_apd_swap_source_and_target(gorio_apd_t* h);
 
-/* setSourceCovariances APD:138-140 / setTargetCovariances APD:143-145: n * 16 doubles */
+/* setSourceCovariances APD:138-140 / setTargetCovariances APD:143-145: n * 16 doubles.  When n differs from the size of the cloud
+ * currently set (or no cloud is set) the call leaves that cloud WITHOUT covariances and returns GORIO_OK: the reference keeps such a
+ * vector but recomputes the covariances at the next align because the sizes differ (APD:149-154). */
 int gorio_apd_set_source_covariances(gorio_apd_t* h, const double* cov4x4, int n);
 int gorio_apd_set_target_covariances(gorio_apd_t* h, const double* cov4x4, int n);
 /* getSourceCovariances APDH:73-75 / getTargetCovariances APDH:77-79.  Returns the number of covariances currently held
@@ -114,7 +118,7 @@ int gorio_apd_get_target_covariances(gorio_apd_t* h, double* cov4x4, int n);
 /* calculate_covariances APD:351-411 for whichever cloud is stale (what computeTransformation does first, APD:149-154) */
 int gorio_apd_calculate_covariances(gorio_apd_t* h);
 /* parity hook: the k neighbour indices (sorted by distance, ties by index) used for cloud `which` (0 source, 1 target);
- * idx holds n*k ints.  Only valid after the covariances were computed by this library. */
+ * idx holds n*k ints.  Only valid after the covariances were computed by this library with params.keep_knn_indices set. */
 int gorio_apd_get_knn_indices(gorio_apd_t* h, int which, int* idx, int n_times_k);
 
 /*
@@ -154,10 +158,11 @@ int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out
 int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double inlier_dist, double* score, double* inlier_fraction);
 
 /* seconds spent inside device kernels of the last align / align_batch, by stage (HIP events on the launch stream):
- * [0] covariance estimation, [1] correspondence search, [2] linearize, [3] LM/GN solve + error trials; plus launch counts
- * in counts[0..3] (either may be NULL).  Filled only after gorio_apd_set_profiling(h, 1). */
+ * [0] k-NN + covariance estimation, [1] correspondence search, [2] linearize, [3] LM/GN solve + error trials, [4] search-index build
+ * (Morton sort, kd refinement, boxes; pruned mode only), [5..7] reserved (0); plus launch-set counts in counts[0..7] (either may be
+ * NULL).  Filled only after gorio_apd_set_profiling(h, 1). */
 int gorio_apd_set_profiling(gorio_apd_t* h, int enable);
-int gorio_apd_get_stage_times(gorio_apd_t* h, double seconds[4], int counts[4]);
+int gorio_apd_get_stage_times(gorio_apd_t* h, double seconds[8], int counts[8]);
 
 #ifdef __cplusplus
 }

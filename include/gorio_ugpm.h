@@ -108,9 +108,10 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
 
 const char* gorio_ugpm_last_error(void);
 
-/* seconds spent in device kernels of the last batch on this thread, by stage: [0] LPM initialisation, [1] Gram / inverse /
- * cross-kernel products, [2] state correlation, [3] LM fits, [4] inference; and kernel launch counts. Either may be NULL. */
-int gorio_ugpm_get_stage_times(double seconds[5], int counts[5]);
+/* seconds spent in device kernels of the last batch on this thread, by stage: [0] LPM initialisation (or the whole LPM output path),
+ * [1] Gram / inverse / cross-kernel products, [2] state correlation, [3] LM fits, [4] inference, [5] the J^T J launches of the LM fits
+ * (a part of [3]), [6] the J^T J launch of the correlation (a part of [2]), [7] reserved; and launch-set counts. Either may be NULL. */
+int gorio_ugpm_get_stage_times(double seconds[8], int counts[8]);
 
 #ifdef __cplusplus
 }

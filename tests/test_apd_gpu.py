@@ -19,6 +19,7 @@ def rel(a, b):
 
 
 def make(gorio, sx, sl, tx, tl, **params):
+    params.setdefault("keep_knn_indices", 1)  # the parity hook behind getKnnIndices (off by default: 80 B of stores per point)
     g = gorio.ApdGicp(**params)
     g.setInputTarget(tx, tl)
     g.setInputSource(sx, sl)
@@ -454,3 +455,33 @@ def test_device_inputs_single_and_batched_match_host_inputs(gpu, gorio):
             assert np.array_equal(o.getCorrespondences()[0], corr)
     for ptr in bufs:
         hip.hipFree(ptr)
+
+
+def test_knn_hook_is_optional_and_changes_nothing(gpu, gorio):
+    """keep_knn_indices only adds the stores of the parity hook: covariances are bit-identical with and without, and without it
+    getKnnIndices is refused (GORIO_ERR_STATE) instead of returning stale data."""
+    xyz, lab = synth.radar_scan(3000, seed=31)
+    for search in (0, 1):
+        a = make(gorio, xyz, lab, xyz, lab, search=search, keep_knn_indices=1)
+        b = make(gorio, xyz, lab, xyz, lab, search=search, keep_knn_indices=0)
+        a.calculateCovariances()
+        b.calculateCovariances()
+        assert np.array_equal(a.getSourceCovariances(), b.getSourceCovariances())
+        assert a.getKnnIndices(0).shape == (3000, 20)
+        with pytest.raises(gorio.GorioError):
+            b.getKnnIndices(0)
+
+
+def test_knn_select_kernel_falls_back_on_massive_ties(gpu, gorio, oracle_apd):
+    """More candidates at the k-th distance than the selection kernel buffers (60 copies of one point, a lattice of equal spacings):
+    those waves are redone by the insertion kernel; lists stay bit-exact, ties to the lowest index."""
+    rng = np.random.default_rng(3)
+    base = rng.uniform(-5, 5, (700, 3)).astype(np.float32)
+    xyz = np.concatenate([base, np.repeat(base[:5], 60, axis=0)])  # 5 points x 61 copies: 60 zero distances each
+    gx, gy, gz = np.meshgrid(np.arange(8, dtype=np.float32), np.arange(8, dtype=np.float32), np.arange(8, dtype=np.float32))
+    xyz = np.concatenate([xyz, np.stack([gx.ravel(), gy.ravel(), gz.ravel()], axis=1) + np.float32(20.0)])  # 26 neighbours within sqrt(3)
+    idx_o, _ = oracle_apd.knn_self(xyz, 20)
+    for search in (0, 1):
+        g = make(gorio, xyz, None, xyz, None, regularization=0, search=search)
+        g.calculateCovariances()
+        assert np.array_equal(g.getKnnIndices(0), idx_o), search

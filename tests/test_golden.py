@@ -43,7 +43,7 @@ def test_oracle_reproduces_ugpm_golden():
 @pytest.mark.gpu
 def test_gpu_matches_apd_golden(gpu, gorio, pose_err):
     g, (sx, sl, tx, tl, _) = _apd_inputs()
-    a = gorio.ApdGicp(corr_dist_threshold=2.0, transformation_epsilon=0.1)
+    a = gorio.ApdGicp(corr_dist_threshold=2.0, transformation_epsilon=0.1, keep_knn_indices=1)
     a.setInputTarget(tx, tl)
     a.setInputSource(sx, sl)
     err, H, b = a.linearize(g["pose"])

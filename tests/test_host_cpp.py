@@ -110,3 +110,23 @@ def test_backend_call_sequence_ugpm(gpu, gorio, tmp_path):
     assert lines[0]["dt"] == pytest.approx(1.0) and lines[0]["cov00"] == pytest.approx(m["cov"][0, 0], rel=1e-12)
     mi = gorio.ugpm_preint_batch([win], vel_bias_std=0.3, gyr_bias_std=0.03)[0][0]
     assert lines[1]["cov00_inflated"] == pytest.approx(mi["cov"][0, 0], rel=1e-12)  # host-side inflation == device-side inflation
+
+
+@pytest.mark.gpu
+def test_host_class_edge_cases(gpu, gorio, tmp_path):
+    """Empty clouds, covariance vectors of the wrong size and re-set clouds through the C++ class (APD:115-155)."""
+    path, frames = _frames(str(tmp_path), n_frames=2)
+    r = subprocess.run([os.path.join(HOST, "test", "edge_cases"), path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["converged"] == 1
+    assert out["empty_source_throws"] == 1 and out["empty_target_throws"] == 1  # nothing stale is registered
+    assert out["cov_mismatch_throws"] == 0  # stored, ignored, recomputed at align (APD:149-154)
+    assert out["T1"] == out["T0"] and out["T2"] == out["T0"]
+    # the class's GPU fitness / inlier fraction equal the ctypes binding's on the same clouds
+    g = gorio.ApdGicp(corr_dist_threshold=2.0, transformation_epsilon=0.1)
+    g.setInputTarget(*frames[0])
+    g.setInputSource(*frames[1])
+    g.align()
+    score, inl = g.getFitnessScore()
+    assert out["fitness"] == pytest.approx(score, rel=1e-12) and out["inlier_fraction"] == pytest.approx(inl, rel=1e-6)

@@ -151,7 +151,7 @@ def test_gpu_real_scan_indices_bit_exact(gpu, gorio, oracle_apd, clouds):
     cs, ct = oracle_apd.calculate_covariances(a, p), oracle_apd.calculate_covariances(b, p)
     err_o, H_o, b_o, corr_o, sqd_o, _ = oracle_apd.linearize(np.eye(4), a, _zeros(a), b, _zeros(b), cs, ct, p)
     for search in (0, 1):
-        g = gorio.ApdGicp(corr_dist_threshold=2.0, search=search)
+        g = gorio.ApdGicp(corr_dist_threshold=2.0, search=search, keep_knn_indices=1)
         g.setInputTarget(b, _zeros(b))
         g.setInputSource(a, _zeros(a))
         err, H, bb = g.linearize(np.eye(4))
