@@ -30,6 +30,8 @@ thread_local int g_stage_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 struct Ctx {  // per-thread, per-device cached buffers
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // the state-correlation chain runs here, beside the two GP fits (a helper thread in the reference, preint.h:939-1064)
+  hipEvent_t ev_jac = nullptr, ev_corr = nullptr;
   double* ws = nullptr;
   size_t ws_cap = 0;
   UgpmWin* d_wins = nullptr;
@@ -233,6 +235,9 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   Ctx& c = g_ctx;
   if (c.device != device) {
     if (c.stream) hipStreamDestroy(c.stream);
+    if (c.stream2) hipStreamDestroy(c.stream2);
+    if (c.ev_jac) hipEventDestroy(c.ev_jac);
+    if (c.ev_corr) hipEventDestroy(c.ev_corr);
     hipFree(c.ws); hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag); hipFree(c.lpm_ws); hipFree(c.lpm_ints); hipFree(c.d_lpm_wins);
     c = Ctx();
     c.device = device;
@@ -242,6 +247,9 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, hi) == hipSuccess) made = true;
     }
     if (!made) UHIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    UHIP(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+    UHIP(hipEventCreateWithFlags(&c.ev_jac, hipEventDisableTiming));
+    UHIP(hipEventCreateWithFlags(&c.ev_corr, hipEventDisableTiming));
     // ata_kernel stages J through up to ~128 KB of dynamic LDS (the default limit is 64 KB)
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::corr_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     UHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ug::infer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 17 * (6 * 160 + 16) * 8) /* S = 160: with the 31 KB of static LDS this is just inside the 160 KB of a CU */);
@@ -502,7 +510,8 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   if (max_S > 0) {
     // J^T J launches: one workgroup per (row slice, tile group, window), see ata_kernel
     auto launch_ata = [&](int which) {
-      Stage st_ata(c, which == 2 ? 6 : 5);
+      hipStream_t sq = which == 2 ? c.stream2 : c.stream;
+      Stage st_ata(c, which == 2 ? 6 : 5, sq);
       const int n = (which == 2 ? 6 : 3) * max_S, T = (n + 15) / 16, ntile = T * (T + 1) / 2;
       const int tpg = which == 2 ? kAtaTilesCorr : kAtaTilesLm;
       const int ng = (ntile + tpg - 1) / tpg;
@@ -511,12 +520,12 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       // LDS as small as the staging needs (53 KB at n = 198): the scan matcher's kernels share the CUs with these workgroups
       auto lds = [&](int kc) { return sizeof(double) * 2 * kc * (npad + 1); };
       if (which == 2) {
-        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesCorr><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
-        else if (npad <= 512) ug::ata_kernel<8, 16, kAtaTilesCorr><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
-        else ug::ata_kernel<16, 8, kAtaTilesCorr><<<grid, 512, lds(8), c.stream>>>(c.d_wins, which, nw, ng);
+        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(c.d_wins, which, nw, ng);
+        else if (npad <= 512) ug::ata_kernel<8, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(c.d_wins, which, nw, ng);
+        else ug::ata_kernel<16, 8, kAtaTilesCorr><<<grid, 512, lds(8), sq>>>(c.d_wins, which, nw, ng);
       } else {
-        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesLm><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);
-        else ug::ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds(16), c.stream>>>(c.d_wins, which, nw, ng);  // n = 3S <= 480
+        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(c.d_wins, which, nw, ng);
+        else ug::ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(c.d_wins, which, nw, ng);  // n = 3S <= 480
       }
     };
     {
@@ -529,13 +538,20 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       ug::gram_kernel<<<dim3(6, nw), 256, 0, c.stream>>>(c.d_wins);
       ug::cross_kernel<<<dim3(12, nw, (std::max(max_G, max_V) + ug::kCrossRows - 1) / ug::kCrossRows), 256, 0, c.stream>>>(c.d_wins);
     }
+    // State correlation at the LPM-initialised state.  The reference assembles the Jacobian synchronously (preint.h:887-937) and
+    // hands J^T J, its factorisation and the inverse diagonal to a helper thread that runs beside the two ceres::Solve calls and is
+    // joined before the first get() (preint.h:939, 1062-1065); here the Jacobian is written on the main stream (the fits then change
+    // the states it is evaluated at) and the rest of the chain runs on a second stream that the inference waits for.
+    ug::corr_jac_kernel<<<dim3(ug::kCorrJacParts, nw), 256, 0, c.stream>>>(c.d_wins);
+    UHIP(hipEventRecord(c.ev_jac, c.stream));
+    UHIP(hipStreamWaitEvent(c.stream2, c.ev_jac, 0));
     {
-      Stage st(c, 2);  // state correlation at the LPM-initialised state (a side thread in the reference, preint.h:939)
-      ug::corr_jac_kernel<<<dim3(ug::kCorrJacParts, nw), 256, 0, c.stream>>>(c.d_wins);
+      Stage st(c, 2, c.stream2);
       launch_ata(2);
-      ug::corr_factor_kernel<<<nw, 512, 0, c.stream>>>(c.d_wins);
-      ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, nw), 256, sizeof(double) * 17 * (6 * max_S + 16), c.stream>>>(c.d_wins);
+      ug::corr_factor_kernel<<<nw, 512, 0, c.stream2>>>(c.d_wins);
+      ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, nw), 256, sizeof(double) * 17 * (6 * max_S + 16), c.stream2>>>(c.d_wins);
     }
+    UHIP(hipEventRecord(c.ev_corr, c.stream2));
     std::vector<int> flags(kWinInts * (size_t)nw);
     for (int problem = 0; problem < 2; ++problem) {  // ceres::Solve #1 (rotation) and #2 (velocity), preint.h:943-967
       Stage st(c, 3);
@@ -563,6 +579,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       }
       ug::lm_end_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, problem, c.d_diag);
     }
+    UHIP(hipStreamWaitEvent(c.stream, c.ev_corr, 0));  // join of the correlation chain (preint.h:1062-1065)
     {
       Stage st(c, 4);
       ug::finish_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
