@@ -51,7 +51,7 @@ APD_SYMBOLS = [
     "gorio_apd_get_target_covariances", "gorio_apd_calculate_covariances", "gorio_apd_get_knn_indices", "gorio_apd_align",
     "gorio_apd_align_batch", "gorio_apd_linearize", "gorio_apd_compute_error", "gorio_apd_get_correspondences",
     "gorio_apd_get_mahalanobis", "gorio_apd_transform_source", "gorio_apd_fitness_score", "gorio_apd_set_profiling",
-    "gorio_apd_get_stage_times",
+    "gorio_apd_get_stage_times", "gorio_apd_set_target_shared", "gorio_comm_get_unique_id", "gorio_apd_comm_init", "gorio_apd_comm_destroy", "gorio_apd_debug_set_shard",
 ]
 
 _lib = None
@@ -177,6 +177,28 @@ class ApdGicp:
     def setInputTargetDevice(self, d_x, d_y, d_z, d_label, n):  # noqa: N802
         _check(self._h, self._lib.gorio_apd_set_target_device(self._h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(d_z), C.c_void_p(d_label or 0), int(n)))
         self._n_tgt = int(n)
+
+    def setInputTargetShared(self, owner):  # noqa: N802 -- gorio_apd_set_target_shared: one device copy of the map for many objects
+        _check(self._h, self._lib.gorio_apd_set_target_shared(self._h, owner._h))
+        self._n_tgt = owner._n_tgt
+
+    # ---- sharded-source mode (RCCL): see include/gorio_apd.h
+    @staticmethod
+    def commUniqueId():  # noqa: N802
+        buf = C.create_string_buffer(128)
+        rc = load_library().gorio_comm_get_unique_id(buf)
+        if rc != 0:
+            raise GorioError(rc, "gorio_comm_get_unique_id failed (librccl missing?)")
+        return buf.raw
+
+    def commInit(self, world_size, rank, unique_id):  # noqa: N802
+        _check(self._h, self._lib.gorio_apd_comm_init(self._h, int(world_size), int(rank), C.c_char_p(bytes(unique_id))))
+
+    def debugSetShard(self, world_size, rank):  # noqa: N802 -- test hook: the partition of a rank without the collectives
+        _check(self._h, self._lib.gorio_apd_debug_set_shard(self._h, int(world_size), int(rank)))
+
+    def commDestroy(self):  # noqa: N802
+        _check(self._h, self._lib.gorio_apd_comm_destroy(self._h))
 
     def clearSource(self):  # noqa: N802
         _check(self._h, self._lib.gorio_apd_clear_source(self._h))

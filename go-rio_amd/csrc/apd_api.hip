@@ -4,14 +4,19 @@
 // their covariances, the per-source-point correspondence state and the device-resident optimiser state, and it drives
 // the kernels of apd_kernels.hip.  No CPU compute path exists here: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/gorio_apd.h"
@@ -47,7 +52,12 @@ struct DevCloud {
   unsigned int* bb = nullptr;
   int idx_cap = 0, keys_cap = 0;
   bool idx_valid = false;
+  int device = 0;
   CloudView view() const { return CloudView{x, y, z, label, p4, cov6, geo_w, n, n_pad, idx}; }
+  DevCloud() = default;
+  DevCloud(const DevCloud&) = delete;
+  DevCloud& operator=(const DevCloud&) = delete;
+  ~DevCloud();  // frees the device buffers: a cloud may be shared by several handles (gorio_apd_set_target_shared) and lives until the last one lets go
 };
 
 }  // namespace
@@ -56,7 +66,7 @@ struct gorio_apd {
   int device = 0;
   hipStream_t stream = nullptr;
   gorio_apd_params params;
-  DevCloud src, tgt;
+  std::shared_ptr<DevCloud> src, tgt;  // never null; tgt may be shared with other handles of the device
   // per-source-point state
   unsigned long long* best_key = nullptr;
   int* corr = nullptr;
@@ -78,6 +88,11 @@ struct gorio_apd {
   IndexJob* d_ijobs = nullptr;
   int ijobs_cap = 0;
   double* d_fit = nullptr;
+  // sharded-source mode (gorio_apd_comm_init): RCCL communicator over the ranks that share one source cloud
+  ncclComm_t comm = nullptr;
+  int comm_world = 1, comm_rank = 0;
+  bool shard_only = false;  // gorio_apd_debug_set_shard: the source partition of a rank without the collectives (test hook)
+  double* d_red = nullptr;  // [32] all-reduce buffer: 28 sums of a linearisation, [28] trial error, [29] scratch
   std::string err;
   // profiling
   bool profiling = false;
@@ -116,10 +131,57 @@ int fail(gorio_apd* h, int code, const std::string& msg) {
 
 int roundup(int v, int m) { return (v + m - 1) / m * m; }
 
-void free_cloud(DevCloud& c) {
+// RCCL is loaded on first use (dlopen): a process that never shards a source never needs librccl, and one that already has a copy
+// mapped (PyTorch ships its own) keeps using that copy.
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
+  });
+  return r;
+}
+
+#define NCCL_TRY(h, expr)                                                                                              \
+  do {                                                                                                                 \
+    ncclResult_t e_ = (expr);                                                                                          \
+    if (e_ != ncclSuccess) return fail(h, GORIO_ERR_NO_DEVICE, std::string(#expr) + ": " + rccl().GetErrorString(e_)); \
+  } while (0)
+
+}  // namespace
+DevCloud::~DevCloud() {
+  DevCloud& c = *this;
+  hipSetDevice(c.device);
   hipFree(c.idx.sx); hipFree(c.idx.sy); hipFree(c.idx.sz); hipFree(c.idx.orig); hipFree(c.idx.tbox); hipFree(c.idx.sbox); hipFree(c.keys); hipFree(c.bb);
   hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.p4); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn); hipFree(c.part_d); hipFree(c.part_i); hipFree(c.redo); hipFree(c.kth);
-  c = DevCloud();
+}
+namespace {
+
+// a cloud about to be overwritten must not be one other handles still look at (gorio_apd_set_target_shared): detach first
+void make_private(gorio_apd* h, std::shared_ptr<DevCloud>& c) {
+  if (c.use_count() > 1) {
+    c = std::make_shared<DevCloud>();
+    c->device = h->device;
+  }
 }
 
 int ensure_cloud(gorio_apd* h, DevCloud& c, int n) {
@@ -288,12 +350,11 @@ void resolve_stage_events(gorio_apd* h) {
 // Build the search accelerator of every listed cloud that lacks one (batched: one launch per sort stage for all clouds).
 int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*>>& clouds) {
   std::vector<std::pair<gorio_apd*, DevCloud*>> todo;
-  for (auto& c : clouds)
-    if (!c.second->idx_valid) {
-      bool dup = false;
-      for (auto& t : todo) dup = dup || t.second == c.second;
-      if (!dup) todo.push_back(c);
-    }
+  {
+    std::unordered_set<DevCloud*> seen;
+    for (auto& c : clouds)
+      if (!c.second->idx_valid && seen.insert(c.second).second) todo.push_back(c);
+  }
   if (todo.empty()) return GORIO_OK;
   const int nj = (int)todo.size();
   std::vector<IndexJob> jobs(nj);
@@ -487,36 +548,46 @@ void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_s
 }
 
 int check_ready(gorio_apd* h) {
-  if (!h->src.present) return fail(h, GORIO_ERR_STATE, "no input source set (setInputSource)");
-  if (!h->tgt.present) return fail(h, GORIO_ERR_STATE, "no input target set (setInputTarget)");
+  if (!h->src->present) return fail(h, GORIO_ERR_STATE, "no input source set (setInputSource)");
+  if (!h->tgt->present) return fail(h, GORIO_ERR_STATE, "no input target set (setInputTarget)");
   const gorio_apd_params& p = h->params;
   if (p.k_correspondences < 1 || p.k_correspondences > 32) return fail(h, GORIO_ERR_UNSUPPORTED, "k_correspondences must be in [1, 32]");
   if (p.regularization < 0 || p.regularization > 4) return fail(h, GORIO_ERR_UNSUPPORTED, "unknown regularization method (the reference aborts here, APD:389-391)");
-  if (h->src.cov_count != h->src.n && h->src.n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "source cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
-  if (h->tgt.cov_count != h->tgt.n && h->tgt.n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "target cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
+  if (h->src->cov_count != h->src->n && h->src->n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "source cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
+  if (h->tgt->cov_count != h->tgt->n && h->tgt->n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "target cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
   return GORIO_OK;
 }
 
 void fill_desc(gorio_apd* h, PairDesc& d, PairState* state, long total_src_waves) {
-  d.src = h->src.view();
-  d.tgt = h->tgt.view();
+  d.src = h->src->view();
+  d.tgt = h->tgt->view();
   d.best_key = h->best_key;
   d.corr = h->corr;
   d.sqd = h->sqd;
   d.omega6 = h->omega6;
   d.partials = h->partials;
   d.state = state;
-  d.nblk = (h->src.n + 255) / 256;
+  d.nblk = (h->src->n + 255) / 256;
   int splits = (int)((8192 + total_src_waves - 1) / total_src_waves);
   if (splits < 1) splits = 1;
   if (splits > 64) splits = 64;
-  int chunk = roundup((h->tgt.n_pad + splits - 1) / splits, kPad);
+  int chunk = roundup((h->tgt->n_pad + splits - 1) / splits, kPad);
   if (chunk < 512) chunk = 512;
   d.nn_chunk = chunk;
-  d.nn_splits = (h->tgt.n_pad + chunk - 1) / chunk;
+  d.nn_splits = (h->tgt->n_pad + chunk - 1) / chunk;
   d.cl_points = h->params.cl_weight_points;
   d.write_omega = 1;
-  d.pad_ = 0;
+  d.shard_lo = 0;
+  d.shard_hi = INT_MAX;
+  if ((h->comm || h->shard_only) && h->comm_world > 1) {
+    // this rank's contiguous part of the query order, in units of 256 (one workgroup): sorted positions for the pruned search (a
+    // spatially compact part of the scan), original indices for the exhaustive one.  Which points a rank owns changes the order of
+    // the fp64 sums, never their value beyond rounding.
+    const int nq = h->params.search == GORIO_SEARCH_PRUNED ? roundup(h->src->n, 512) : h->src->n;
+    const long nb = (nq + 255) / 256;
+    d.shard_lo = (int)(nb * h->comm_rank / h->comm_world) * 256;
+    d.shard_hi = h->comm_rank == h->comm_world - 1 ? INT_MAX : (int)(nb * (h->comm_rank + 1) / h->comm_world) * 256;
+  }
 }
 
 void init_state(PairState& s, const double* T16) {
@@ -562,24 +633,36 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
   gorio_apd* lead = hs[0];
   if (!lead) return GORIO_ERR_INVALID;
   HIP_TRY(lead, hipSetDevice(lead->device));
+  for (int q = 0; q < count; ++q)
+    if (hs[q] && hs[q]->comm && count != 1) return fail(lead, GORIO_ERR_INVALID, "a handle with a communicator (sharded source) cannot be part of a batch");
+  std::unordered_set<gorio_apd*> distinct;
   for (int q = 0; q < count; ++q) {
     gorio_apd* h = hs[q];
     if (!h) return fail(lead, GORIO_ERR_INVALID, "null handle in batch");
     if (h->device != lead->device) return fail(lead, GORIO_ERR_INVALID, "all handles of a batch must live on one device");
+    if (!distinct.insert(h).second) return fail(lead, GORIO_ERR_INVALID, "the same handle appears twice in a batch (its buffers would be raced on)");
+    {  // one launch set advances all pairs: everything but cl_weight_points (per handle) must agree with the first handle
+      gorio_apd_params a = h->params, b = lead->params;
+      a.cl_weight_points = b.cl_weight_points = 0;
+      if (std::memcmp(&a, &b, sizeof(a)) != 0) return fail(lead, GORIO_ERR_INVALID, "all handles of a batch must carry the same parameters (cl_weight_points excepted)");
+    }
     int rc = check_ready(h);
     if (rc) {
       if (h != lead) lead->err = h->err;
       return rc;
     }
-    rc = ensure_points(h, h->src.n);
+    rc = ensure_points(h, h->src->n);
     if (rc) return rc;
   }
   // APD:149-154: covariances of whichever cloud is stale
   std::vector<std::pair<gorio_apd*, DevCloud*>> todo;
-  for (int q = 0; q < count; ++q) {
-    gorio_apd* h = hs[q];
-    if (h->src.cov_count != h->src.n) todo.emplace_back(h, &h->src);
-    if (h->tgt.cov_count != h->tgt.n) todo.emplace_back(h, &h->tgt);
+  {
+    std::unordered_set<DevCloud*> seen;  // a target shared by many handles of the batch is estimated once
+    for (int q = 0; q < count; ++q) {
+      gorio_apd* h = hs[q];
+      if (h->src->cov_count != h->src->n && seen.insert(h->src.get()).second) todo.emplace_back(h, h->src.get());
+      if (h->tgt->cov_count != h->tgt->n && seen.insert(h->tgt.get()).second) todo.emplace_back(h, h->tgt.get());
+    }
   }
   int rc = run_covariances(lead, todo);
   if (rc) return rc;
@@ -587,8 +670,8 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
   if (lead->params.search == GORIO_SEARCH_PRUNED) {
     std::vector<std::pair<gorio_apd*, DevCloud*>> all;
     for (int q = 0; q < count; ++q) {
-      all.emplace_back(hs[q], &hs[q]->src);
-      all.emplace_back(hs[q], &hs[q]->tgt);
+      all.emplace_back(hs[q], hs[q]->src.get());
+      all.emplace_back(hs[q], hs[q]->tgt.get());
     }
     rc = run_index_build(lead, all);
     if (rc) return rc;
@@ -598,8 +681,8 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
   long total_src_waves = 0;
   int max_n = 0;
   for (int q = 0; q < count; ++q) {
-    total_src_waves += (hs[q]->src.n + 63) / 64;
-    if (hs[q]->src.n > max_n) max_n = hs[q]->src.n;
+    total_src_waves += (hs[q]->src->n + 63) / 64;
+    if (hs[q]->src->n > max_n) max_n = hs[q]->src->n;
   }
   std::vector<PairDesc> descs(count);
   std::vector<PairState> states(count);
@@ -623,6 +706,47 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
 
   const ApdConsts cst = make_consts(lead->params);
   const dim3 g_nn((max_n + 255) / 256, max_splits, count), g_lin((max_n + 255) / 256, 1, count), g_lm(count);
+  if (lead->comm) {  // sharded source: the same loop, cut at the two all-reduces (count == 1, checked above)
+    Rccl& R = rccl();
+    const int max_it = lead->params.max_iterations;
+    const bool lm = lead->params.optimizer == GORIO_OPT_LEVENBERG_MARQUARDT;
+    for (int it = 0; it < max_it; ++it) {
+      launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), 1);
+      linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst);
+      shard_reduce_partials_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red);
+      NCCL_TRY(lead, R.AllReduce(lead->d_red, lead->d_red, 28, ncclDouble, ncclSum, lead->comm, lead->stream));  // THE collective: H, b, error
+      shard_begin_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red, cst, 0);
+      int trials = 0;
+      bool active = lm;
+      while (active) {
+        // two trial slots per round trip: a Levenberg-Marquardt step is almost always decided by the first or second trial; every rank
+        // reads the same flags, so every rank enqueues the same sequence of collectives
+        for (int t = 0; t < 2 && trials < lead->params.lm_max_iterations; ++t, ++trials) {
+          shard_trial_error_kernel<<<1, 1024, 0, lead->stream>>>(lead->d_desc, lead->d_red + 28, cst, 0);
+          NCCL_TRY(lead, R.AllReduce(lead->d_red + 28, lead->d_red + 28, 1, ncclDouble, ncclSum, lead->comm, lead->stream));
+          shard_trial_decide_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red + 28, cst, 0);
+        }
+        HIP_TRY(lead, hipMemcpyAsync(&states[0], lead->d_state, sizeof(PairState), hipMemcpyDeviceToHost, lead->stream));
+        HIP_TRY(lead, hipStreamSynchronize(lead->stream));
+        active = states[0].trial_active != 0 && trials < lead->params.lm_max_iterations;
+      }
+      if (lm) shard_trial_decide_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red + 28, cst, 1);  // end-of-iteration bookkeeping
+      HIP_TRY(lead, hipGetLastError());
+      HIP_TRY(lead, hipMemcpyAsync(&states[0], lead->d_state, sizeof(PairState), hipMemcpyDeviceToHost, lead->stream));
+      HIP_TRY(lead, hipStreamSynchronize(lead->stream));
+      if (states[0].done) break;
+    }
+    const PairState& s0 = states[0];
+    for (int i = 0; i < 12; ++i) T_out[i] = (float)s0.x0[i];
+    T_out[12] = 0.f; T_out[13] = 0.f; T_out[14] = 0.f; T_out[15] = 1.f;
+    if (H_out) std::memcpy(H_out, s0.Hfin, sizeof(double) * 36);
+    if (converged) converged[0] = s0.converged;
+    if (nr_iterations) nr_iterations[0] = s0.nr_iterations;
+    if (n_linearize) n_linearize[0] = s0.n_linearize;
+    if (s0.lm_failed) lead->err = "lm not converged!!";
+    resolve_stage_events(lead);
+    return GORIO_OK;
+  }
   int launched = 0;
   int chunk_iters = 4;
   const int max_it = lead->params.max_iterations;
@@ -666,7 +790,7 @@ int single_desc(gorio_apd* h) {
   int rc = ensure_batch(h, 1);
   if (rc) return rc;
   PairDesc d;
-  fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
+  fill_desc(h, d, h->d_state, (h->src->n + 63) / 64);
   HIP_TRY(h, hipMemcpyAsync(h->d_desc, &d, sizeof(PairDesc), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GORIO_OK;
@@ -680,6 +804,7 @@ extern "C" {
 
 void gorio_apd_default_params(gorio_apd_params* p) {
   if (!p) return;
+  std::memset(p, 0, sizeof(*p));
   p->k_correspondences = 20;
   p->regularization = GORIO_REG_PLANE;
   p->dist_var = 0.86;
@@ -707,10 +832,13 @@ int gorio_apd_create(gorio_apd_t** out, int device) {
   gorio_apd* h = new (std::nothrow) gorio_apd();
   if (!h) return GORIO_ERR_ALLOC;
   h->device = device;
+  h->src = std::make_shared<DevCloud>();
+  h->tgt = std::make_shared<DevCloud>();
+  h->src->device = h->tgt->device = device;
   gorio_apd_default_params(&h->params);
   h->stream = device_stream(device);
   if (!h->stream || hipMalloc(&h->d_state, sizeof(PairState)) != hipSuccess ||
-      hipMalloc(&h->d_fit, sizeof(double) * 4) != hipSuccess) {
+      hipMalloc(&h->d_fit, sizeof(double) * 4) != hipSuccess || hipMalloc(&h->d_red, sizeof(double) * 32) != hipSuccess) {
     delete h;
     return GORIO_ERR_NO_DEVICE;
   }
@@ -722,8 +850,10 @@ void gorio_apd_destroy(gorio_apd_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  free_cloud(h->src);
-  free_cloud(h->tgt);
+  if (h->comm && rccl().ok) rccl().CommDestroy(h->comm);
+  hipFree(h->d_red);
+  h->src.reset();
+  h->tgt.reset();
   hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
   hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_ijobs); hipFree(h->d_fit); hipFree(h->d_copy_jobs);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
@@ -737,7 +867,13 @@ int gorio_apd_set_params(gorio_apd_t* h, const gorio_apd_params* p) {
   if (p->k_correspondences < 1 || p->k_correspondences > 32) return fail(h, GORIO_ERR_UNSUPPORTED, "k_correspondences must be in [1, 32]");
   if (p->regularization < 0 || p->regularization > 4) return fail(h, GORIO_ERR_UNSUPPORTED, "unknown regularization method");
   if (p->optimizer != GORIO_OPT_GAUSS_NEWTON && p->optimizer != GORIO_OPT_LEVENBERG_MARQUARDT) return fail(h, GORIO_ERR_INVALID, "unknown optimizer");
-  h->params = *p;
+  std::memset(&h->params, 0, sizeof(h->params));  // padding bytes stay zero so whole-struct comparisons (batch validation) are meaningful
+  h->params.k_correspondences = p->k_correspondences; h->params.regularization = p->regularization;
+  h->params.dist_var = p->dist_var; h->params.azimuth_var = p->azimuth_var; h->params.elevation_var = p->elevation_var;
+  h->params.corr_dist_threshold = p->corr_dist_threshold; h->params.max_iterations = p->max_iterations;
+  h->params.rotation_epsilon = p->rotation_epsilon; h->params.transformation_epsilon = p->transformation_epsilon;
+  h->params.optimizer = p->optimizer; h->params.lm_max_iterations = p->lm_max_iterations; h->params.lm_init_lambda_factor = p->lm_init_lambda_factor;
+  h->params.search = p->search; h->params.cl_weight_points = p->cl_weight_points; h->params.keep_knn_indices = p->keep_knn_indices;
   return GORIO_OK;
 }
 
@@ -750,22 +886,26 @@ int gorio_apd_get_params(const gorio_apd_t* h, gorio_apd_params* p) {
 int gorio_apd_set_source(gorio_apd_t* h, const float* xyz, const float* label, int n, int stride) {
   if (!h) return GORIO_ERR_INVALID;
   h->corr_valid = false;
-  return upload_cloud(h, h->src, xyz, label, n, stride);
+  make_private(h, h->src);
+  return upload_cloud(h, *h->src, xyz, label, n, stride);
 }
 int gorio_apd_set_target(gorio_apd_t* h, const float* xyz, const float* label, int n, int stride) {
   if (!h) return GORIO_ERR_INVALID;
   h->corr_valid = false;
-  return upload_cloud(h, h->tgt, xyz, label, n, stride);
+  make_private(h, h->tgt);
+  return upload_cloud(h, *h->tgt, xyz, label, n, stride);
 }
 int gorio_apd_set_source_device(gorio_apd_t* h, const float* dx, const float* dy, const float* dz, const float* dl, int n) {
   if (!h) return GORIO_ERR_INVALID;
   h->corr_valid = false;
-  return upload_cloud_device(h, h->src, dx, dy, dz, dl, n);
+  make_private(h, h->src);
+  return upload_cloud_device(h, *h->src, dx, dy, dz, dl, n);
 }
 int gorio_apd_set_target_device(gorio_apd_t* h, const float* dx, const float* dy, const float* dz, const float* dl, int n) {
   if (!h) return GORIO_ERR_INVALID;
   h->corr_valid = false;
-  return upload_cloud_device(h, h->tgt, dx, dy, dz, dl, n);
+  make_private(h, h->tgt);
+  return upload_cloud_device(h, *h->tgt, dx, dy, dz, dl, n);
 }
 
 int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const gorio_apd_device_cloud* source, const gorio_apd_device_cloud* target) {
@@ -785,7 +925,8 @@ int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const go
       if (!arr) continue;
       const gorio_apd_device_cloud& in = arr[q];
       if (!in.x || !in.y || !in.z || in.n <= 0) return fail(lead, GORIO_ERR_INVALID, "set_clouds_device_batch: bad cloud arguments");
-      DevCloud& c = side == 0 ? h->src : h->tgt;
+      make_private(h, side == 0 ? h->src : h->tgt);
+      DevCloud& c = side == 0 ? *h->src : *h->tgt;
       int rc = ensure_cloud(h, c, in.n);
       if (rc) {
         if (h != lead) lead->err = h->err;
@@ -816,14 +957,25 @@ int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const go
 
 int gorio_apd_clear_source(gorio_apd_t* h) {
   if (!h) return GORIO_ERR_INVALID;
-  h->src.present = false; h->src.n = 0; h->src.cov_count = 0; h->corr_valid = false;  // APD:101-105
+  make_private(h, h->src);
+  h->src->present = false; h->src->n = 0; h->src->cov_count = 0; h->corr_valid = false;  // APD:101-105
   return GORIO_OK;
 }
 int gorio_apd_clear_target(gorio_apd_t* h) {
   if (!h) return GORIO_ERR_INVALID;
-  h->tgt.present = false; h->tgt.n = 0; h->tgt.cov_count = 0; h->corr_valid = false;  // APD:107-112
+  make_private(h, h->tgt);
+  h->tgt->present = false; h->tgt->n = 0; h->tgt->cov_count = 0; h->corr_valid = false;  // APD:107-112
   return GORIO_OK;
 }
+int gorio_apd_set_target_shared(gorio_apd_t* h, gorio_apd_t* owner) {
+  if (!h || !owner) return GORIO_ERR_INVALID;
+  if (h->device != owner->device) return fail(h, GORIO_ERR_INVALID, "set_target_shared: both handles must live on one device");
+  if (!owner->tgt->present) return fail(h, GORIO_ERR_STATE, "set_target_shared: the owner has no input target");
+  h->tgt = owner->tgt;  // points, covariances, search index: one copy on the device, alive until the last handle lets go of it
+  h->corr_valid = false;
+  return GORIO_OK;
+}
+
 int gorio_apd_swap_source_and_target(gorio_apd_t* h) {
   if (!h) return GORIO_ERR_INVALID;
   std::swap(h->src, h->tgt);  // APD:90-92: clouds, trees and covariances change sides
@@ -856,8 +1008,8 @@ static int set_covs(gorio_apd* h, DevCloud& c, const double* cov, int n) {
   return GORIO_OK;
 }
 
-int gorio_apd_set_source_covariances(gorio_apd_t* h, const double* cov, int n) { return h ? set_covs(h, h->src, cov, n) : GORIO_ERR_INVALID; }
-int gorio_apd_set_target_covariances(gorio_apd_t* h, const double* cov, int n) { return h ? set_covs(h, h->tgt, cov, n) : GORIO_ERR_INVALID; }
+int gorio_apd_set_source_covariances(gorio_apd_t* h, const double* cov, int n) { return h ? set_covs(h, *h->src, cov, n) : GORIO_ERR_INVALID; }
+int gorio_apd_set_target_covariances(gorio_apd_t* h, const double* cov, int n) { return h ? set_covs(h, *h->tgt, cov, n) : GORIO_ERR_INVALID; }
 
 static int get_covs(gorio_apd* h, DevCloud& c, double* cov, int n) {
   const int cnt = c.present ? c.cov_count : 0;
@@ -877,15 +1029,15 @@ static int get_covs(gorio_apd* h, DevCloud& c, double* cov, int n) {
   }
   return cnt;
 }
-int gorio_apd_get_source_covariances(gorio_apd_t* h, double* cov, int n) { return h ? get_covs(h, h->src, cov, n) : GORIO_ERR_INVALID; }
-int gorio_apd_get_target_covariances(gorio_apd_t* h, double* cov, int n) { return h ? get_covs(h, h->tgt, cov, n) : GORIO_ERR_INVALID; }
+int gorio_apd_get_source_covariances(gorio_apd_t* h, double* cov, int n) { return h ? get_covs(h, *h->src, cov, n) : GORIO_ERR_INVALID; }
+int gorio_apd_get_target_covariances(gorio_apd_t* h, double* cov, int n) { return h ? get_covs(h, *h->tgt, cov, n) : GORIO_ERR_INVALID; }
 
 int gorio_apd_calculate_covariances(gorio_apd_t* h) {
   if (!h) return GORIO_ERR_INVALID;
   HIP_TRY(h, hipSetDevice(h->device));
   const gorio_apd_params& p = h->params;
   std::vector<std::pair<gorio_apd*, DevCloud*>> todo;
-  for (DevCloud* c : {&h->src, &h->tgt}) {
+  for (DevCloud* c : {h->src.get(), h->tgt.get()}) {
     if (c->present && c->cov_count != c->n) {
       if (c->n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
       todo.emplace_back(h, c);
@@ -900,7 +1052,7 @@ int gorio_apd_calculate_covariances(gorio_apd_t* h) {
 
 int gorio_apd_get_knn_indices(gorio_apd_t* h, int which, int* idx, int n_times_k) {
   if (!h || !idx) return GORIO_ERR_INVALID;
-  DevCloud& c = which == 0 ? h->src : h->tgt;
+  DevCloud& c = which == 0 ? *h->src : *h->tgt;
   if (!c.present || !c.knn || !c.knn_valid || c.cov_count != c.n) return fail(h, GORIO_ERR_STATE, "no k-NN result held for this cloud (set params.keep_knn_indices before the covariances are computed)");
   if (n_times_k != c.n * c.knn_k) return fail(h, GORIO_ERR_INVALID, "get_knn_indices: size mismatch");
   HIP_TRY(h, hipSetDevice(h->device));
@@ -924,12 +1076,12 @@ int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b
   HIP_TRY(h, hipSetDevice(h->device));
   int rc = check_ready(h);
   if (rc) return rc;
-  rc = ensure_points(h, h->src.n);
+  rc = ensure_points(h, h->src->n);
   if (rc) return rc;
   rc = gorio_apd_calculate_covariances(h);
   if (rc) return rc;
   if (h->params.search == GORIO_SEARCH_PRUNED) {
-    std::vector<std::pair<gorio_apd*, DevCloud*>> all = {{h, &h->src}, {h, &h->tgt}};
+    std::vector<std::pair<gorio_apd*, DevCloud*>> all = {{h, h->src.get()}, {h, h->tgt.get()}};
     rc = run_index_build(h, all);
     if (rc) return rc;
   }
@@ -938,14 +1090,20 @@ int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b
   PairState s;
   init_state(s, T);
   HIP_TRY(h, hipMemcpyAsync(h->d_state, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->best_key, 0xff, sizeof(unsigned long long) * h->src.n, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->best_key, 0xff, sizeof(unsigned long long) * h->src->n, h->stream));
   const ApdConsts cst = make_consts(h->params);
   PairDesc d;
-  fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
-  const int nbx = (h->src.n + 255) / 256;
-  launch_nn(h, h->d_desc, dim3(nbx, d.nn_splits, 1), roundup(h->src.n, 512), 1);
+  fill_desc(h, d, h->d_state, (h->src->n + 63) / 64);
+  const int nbx = (h->src->n + 255) / 256;
+  launch_nn(h, h->d_desc, dim3(nbx, d.nn_splits, 1), roundup(h->src->n, 512), 1);
   linearize_kernel<<<dim3(nbx, 1, 1), 256, 0, h->stream>>>(h->d_desc, cst);
-  lm_solve_kernel<<<1, 1024, 0, h->stream>>>(h->d_desc, cst, 1);
+  if (h->comm) {  // every rank of the communicator makes this call; H, b and the error come back summed over all of them
+    shard_reduce_partials_kernel<<<1, 64, 0, h->stream>>>(h->d_desc, h->d_red);
+    NCCL_TRY(h, rccl().AllReduce(h->d_red, h->d_red, 28, ncclDouble, ncclSum, h->comm, h->stream));
+    shard_begin_kernel<<<1, 64, 0, h->stream>>>(h->d_desc, h->d_red, cst, 1);
+  } else {
+    lm_solve_kernel<<<1, 1024, 0, h->stream>>>(h->d_desc, cst, 1);
+  }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(&s, h->d_state, sizeof(s), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -969,9 +1127,17 @@ int gorio_apd_compute_error(gorio_apd_t* h, const double T[16], double* error) {
   for (int i = 0; i < 16; ++i) xi[i] = T[i];
   HIP_TRY(h, hipMemcpyAsync(reinterpret_cast<char*>(h->d_state) + offsetof(PairState, xi), xi, sizeof(xi), hipMemcpyHostToDevice, h->stream));
   const ApdConsts cst = make_consts(h->params);
+  double yi = 0.0;
+  if (h->comm) {
+    shard_trial_error_kernel<<<1, 1024, 0, h->stream>>>(h->d_desc, h->d_red + 28, cst, 2);
+    NCCL_TRY(h, rccl().AllReduce(h->d_red + 28, h->d_red + 28, 1, ncclDouble, ncclSum, h->comm, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&yi, h->d_red + 28, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *error = yi;
+    return GORIO_OK;
+  }
   lm_solve_kernel<<<1, 1024, 0, h->stream>>>(h->d_desc, cst, 2);
   HIP_TRY(h, hipGetLastError());
-  double yi = 0.0;
   HIP_TRY(h, hipMemcpyAsync(&yi, reinterpret_cast<char*>(h->d_state) + offsetof(PairState, yi), sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   *error = yi;
@@ -981,7 +1147,7 @@ int gorio_apd_compute_error(gorio_apd_t* h, const double T[16], double* error) {
 int gorio_apd_get_correspondences(gorio_apd_t* h, int* corr, float* sq_dist, int n) {
   if (!h) return GORIO_ERR_INVALID;
   if (!h->corr_valid) return fail(h, GORIO_ERR_STATE, "no correspondences held");
-  if (n != h->src.n) return fail(h, GORIO_ERR_INVALID, "get_correspondences: size mismatch");
+  if (n != h->src->n) return fail(h, GORIO_ERR_INVALID, "get_correspondences: size mismatch");
   HIP_TRY(h, hipSetDevice(h->device));
   if (corr) HIP_TRY(h, hipMemcpyAsync(corr, h->corr, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
   if (sq_dist) HIP_TRY(h, hipMemcpyAsync(sq_dist, h->sqd, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
@@ -992,7 +1158,7 @@ int gorio_apd_get_correspondences(gorio_apd_t* h, int* corr, float* sq_dist, int
 int gorio_apd_get_mahalanobis(gorio_apd_t* h, double* maha, int n) {
   if (!h || !maha) return GORIO_ERR_INVALID;
   if (!h->corr_valid || !h->omega_valid) return fail(h, GORIO_ERR_STATE, "no Mahalanobis matrices held (a Gauss-Newton align does not materialise them: call gorio_apd_linearize)");
-  if (n != h->src.n) return fail(h, GORIO_ERR_INVALID, "get_mahalanobis: size mismatch");
+  if (n != h->src->n) return fail(h, GORIO_ERR_INVALID, "get_mahalanobis: size mismatch");
   HIP_TRY(h, hipSetDevice(h->device));
   std::vector<double> o6((size_t)n * 6);
   HIP_TRY(h, hipMemcpyAsync(o6.data(), h->omega6, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, h->stream));
@@ -1010,14 +1176,14 @@ int gorio_apd_get_mahalanobis(gorio_apd_t* h, double* maha, int n) {
 
 int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out, int n, int stride) {
   if (!h || !T || !xyz_out) return GORIO_ERR_INVALID;
-  if (!h->src.present || n != h->src.n) return fail(h, GORIO_ERR_STATE, "transform_source: no matching source cloud");
+  if (!h->src->present || n != h->src->n) return fail(h, GORIO_ERR_STATE, "transform_source: no matching source cloud");
   if (stride < 12 || stride % 4) return fail(h, GORIO_ERR_INVALID, "transform_source: bad stride");
   HIP_TRY(h, hipSetDevice(h->device));
   float* d_out = nullptr;
   HIP_TRY(h, hipMalloc(&d_out, sizeof(float) * 3 * (size_t)n));
   TfArg tf;
   for (int i = 0; i < 12; ++i) tf.m[i] = T[i];
-  transform_cloud_kernel<<<(n + 255) / 256, 256, 0, h->stream>>>(h->src.x, h->src.y, h->src.z, n, tf, d_out);
+  transform_cloud_kernel<<<(n + 255) / 256, 256, 0, h->stream>>>(h->src->x, h->src->y, h->src->z, n, tf, d_out);
   std::vector<float> tmp((size_t)n * 3);
   hipError_t e = hipMemcpyAsync(tmp.data(), d_out, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1033,13 +1199,13 @@ int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out
 
 int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double inlier_dist, double* score, double* inlier_fraction) {
   if (!h || !T || !score) return GORIO_ERR_INVALID;
-  if (!h->src.present || !h->tgt.present) return fail(h, GORIO_ERR_STATE, "fitness_score: clouds not set");
+  if (!h->src->present || !h->tgt->present) return fail(h, GORIO_ERR_STATE, "fitness_score: clouds not set");
   HIP_TRY(h, hipSetDevice(h->device));
-  int rc = ensure_points(h, h->src.n);
+  int rc = ensure_points(h, h->src->n);
   if (rc) return rc;
   const bool pruned = h->params.search == GORIO_SEARCH_PRUNED;
   if (pruned) {  // the same exact branch-and-bound search as the registration (matters for 100 k-point maps)
-    std::vector<std::pair<gorio_apd*, DevCloud*>> both = {{h, &h->src}, {h, &h->tgt}};
+    std::vector<std::pair<gorio_apd*, DevCloud*>> both = {{h, h->src.get()}, {h, h->tgt.get()}};
     rc = run_index_build(h, both);
     if (rc) return rc;
   }
@@ -1050,7 +1216,7 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
   for (int i = 0; i < 16; ++i) Td[i] = (double)T[i];
   init_state(s, Td);
   for (int i = 0; i < 12; ++i) s.Tf[i] = T[i];
-  const int nbx = (h->src.n + 255) / 256;
+  const int nbx = (h->src->n + 255) / 256;
   if ((size_t)nbx * 3 > h->fit_cap) {
     hipFree(h->d_fit);
     h->d_fit = nullptr;
@@ -1059,9 +1225,9 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
     h->fit_cap = (size_t)nbx * 3;
   }
   HIP_TRY(h, hipMemcpyAsync(h->d_state, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->best_key, 0xff, sizeof(unsigned long long) * h->src.n, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->best_key, 0xff, sizeof(unsigned long long) * h->src->n, h->stream));
   PairDesc d;
-  fill_desc(h, d, h->d_state, (h->src.n + 63) / 64);
+  fill_desc(h, d, h->d_state, (h->src->n + 63) / 64);
   if (!(inlier_dist > 0.0)) inlier_dist = 0.5;  // const double max_correspondence_dist = 0.5, SMO:677
   const double inlier_sq = inlier_dist * inlier_dist;
   if (pruned) {
@@ -1072,14 +1238,14 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
       bf = (float)lim;
       if ((double)bf < lim) bf = std::nextafterf(bf, FLT_MAX);
     }
-    const int waves = (h->src.n + 63) / 64;
+    const int waves = (h->src->n + 63) / 64;
     int splits = 4096 / (waves > 0 ? waves : 1);
     splits = std::min(16, std::max(1, splits));
-    nn_search_pruned_kernel<<<dim3((roundup(h->src.n, 512) + 255) / 256, splits, 1), 256, 0, h->stream>>>(h->d_desc, bf);
+    nn_search_pruned_kernel<<<dim3((roundup(h->src->n, 512) + 255) / 256, splits, 1), 256, 0, h->stream>>>(h->d_desc, bf);
   } else {
     nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
   }
-  fitness_kernel<<<nbx, 256, 0, h->stream>>>(h->best_key, h->src.n, max_range, inlier_sq, h->d_fit);
+  fitness_kernel<<<nbx, 256, 0, h->stream>>>(h->best_key, h->src->n, max_range, inlier_sq, h->d_fit);
   HIP_TRY(h, hipGetLastError());
   std::vector<double> part((size_t)nbx * 3);
   HIP_TRY(h, hipMemcpyAsync(part.data(), h->d_fit, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
@@ -1089,7 +1255,63 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
   for (int bk = 0; bk < nbx; ++bk)
     for (int q = 0; q < 3; ++q) out[q] += part[(size_t)bk * 3 + q];
   *score = out[1] > 0 ? out[0] / out[1] : DBL_MAX;  // pcl: returns max double when no correspondence is in range
-  if (inlier_fraction) *inlier_fraction = out[2] / (double)h->src.n;
+  if (inlier_fraction) *inlier_fraction = out[2] / (double)h->src->n;
+  return GORIO_OK;
+}
+
+int gorio_comm_get_unique_id(char id[128]) {
+  if (!id) return GORIO_ERR_INVALID;
+  Rccl& R = rccl();
+  if (!R.ok) return GORIO_ERR_NO_DEVICE;
+  ncclUniqueId u;
+  if (R.GetUniqueId(&u) != ncclSuccess) return GORIO_ERR_NO_DEVICE;
+  static_assert(sizeof(u) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id, &u, 128);
+  return GORIO_OK;
+}
+
+int gorio_apd_comm_init(gorio_apd_t* h, int world_size, int rank, const char id[128]) {
+  if (!h || !id || world_size < 1 || rank < 0 || rank >= world_size) return GORIO_ERR_INVALID;
+  Rccl& R = rccl();
+  if (!R.ok) return fail(h, GORIO_ERR_NO_DEVICE, "librccl could not be loaded");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->comm) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    R.CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
+  ncclUniqueId u;
+  std::memcpy(&u, id, 128);
+  NCCL_TRY(h, R.CommInitRank(&h->comm, world_size, u, rank));
+  h->comm_world = world_size;
+  h->comm_rank = rank;
+  h->shard_only = false;
+  h->corr_valid = false;
+  return GORIO_OK;
+}
+
+int gorio_apd_debug_set_shard(gorio_apd_t* h, int world_size, int rank) {
+  if (!h || world_size < 1 || rank < 0 || rank >= world_size) return GORIO_ERR_INVALID;
+  if (h->comm) return fail(h, GORIO_ERR_STATE, "debug_set_shard: the handle has a communicator");
+  h->comm_world = world_size;
+  h->comm_rank = rank;
+  h->shard_only = world_size > 1;
+  h->corr_valid = false;
+  return GORIO_OK;
+}
+
+int gorio_apd_comm_destroy(gorio_apd_t* h) {
+  if (!h) return GORIO_ERR_INVALID;
+  if (h->comm) {
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (rccl().ok) rccl().CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
+  h->comm_world = 1;
+  h->comm_rank = 0;
+  h->shard_only = false;
+  h->corr_valid = false;
   return GORIO_OK;
 }
 

@@ -63,6 +63,14 @@ struct PairState {
   int n_linearize;  // linearize() calls
   int n_error;      // compute_error() trials
   int pad_;
+  // sharded-source mode (gorio_apd_comm_init): the LM trial loop is cut into launches around the all-reduces, so its locals live here
+  double sd[6];      // last solved step d (LSQ:138)
+  double sdelta[16]; // its delta transform (LSQ:140-142)
+  double nu;         // LSQ:135
+  int trial_active;  // an LM trial pose is waiting for its (all-reduced) error
+  int ok;            // this outer iteration produced a step (LSQ:71)
+  int trial;         // trials consumed in this outer iteration
+  int pad2_;
 };
 
 struct PairDesc {
@@ -78,6 +86,9 @@ struct PairDesc {
   int nn_splits;     // target range split count for nn_search_kernel
   int nn_chunk;      // candidates per split (multiple of 16)
   int cl_points;     // N of cl_weight = 1/N (APD:273); 0 = src.n
+  int shard_lo;      // sharded-source mode: this rank searches only query positions [shard_lo, shard_hi) -- sorted positions for the
+  int shard_hi;      // pruned search, original indices for the exhaustive one (multiples of 256 or INT_MAX); points outside keep an
+                     // armed key, so linearize / compute_error see them as "no correspondence" and add nothing
   int write_omega;   // store the Mahalanobis matrices (mahalanobis_, APDH:111).  Only compute_error reads them back (LM trials, the
                      // parity hooks); a Gauss-Newton align never does, so it skips the 48 B per point per linearisation
   int pad_;

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   const SearchIndex& ti = pd.tgt.idx;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= si.n) return;
+  if ((int)(blockIdx.x * 256) < pd.shard_lo || (int)(blockIdx.x * 256) >= pd.shard_hi) return;  // another rank's part of the source
   const int lane = threadIdx.x & 63;
   const int pq = p < si.n ? p : si.n - 1;
   float qx, qy, qz;

@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const PairDesc* __restri
   if (st->done) return;
   const int n = pd.src.n;
   if (blockIdx.x * 256 >= n) return;
+  if ((int)(blockIdx.x * 256) < pd.shard_lo || (int)(blockIdx.x * 256) >= pd.shard_hi) return;  // another rank's part of the source
   const int split = blockIdx.y;
   if (split >= pd.nn_splits) return;
   const int j0 = split * pd.nn_chunk;
@@ -794,6 +795,168 @@ __global__ __launch_bounds__(1024) void lm_solve_kernel(const PairDesc* __restri
     __threadfence();
     st->done = done;
   }
+}
+
+// ----------------------------------------------------------------------------------------------- sharded-source optimiser
+//
+// "One large co-registration" (SURVEY 8e): the source points are split over the ranks of an RCCL communicator, the target (map) is
+// replicated.  Every rank runs the same launch sequence on its own stream; the ONLY exchange is an in-place ncclAllReduce of 28
+// doubles (upper triangle of H, b, error) per linearisation and of 1 double per Levenberg-Marquardt trial.  lm_solve_kernel's body is
+// cut at those two points: its locals (d, delta, lambda, nu) live in PairState, every rank takes the same decisions from the same
+// reduced numbers, so the poses stay bit-identical on all ranks without a broadcast.
+
+// sum of this rank's block partials in block order -> red[28] (then all-reduced in place).  grid 1, block 64
+__global__ __launch_bounds__(64) void shard_reduce_partials_kernel(const PairDesc* __restrict__ descs, double* __restrict__ red) {
+  const PairDesc& pd = descs[0];
+  if (pd.state->done) return;
+  if (threadIdx.x < 28) {
+    double s = 0.0;
+    for (int bk = 0; bk < pd.nblk; ++bk) s += pd.partials[(size_t)bk * 28 + threadIdx.x];
+    red[threadIdx.x] = s;
+  }
+}
+
+__device__ void shard_prepare_trial(PairState* __restrict__ st, double lambda) {
+  double Hl[36], nb[6];
+  for (int a = 0; a < 36; ++a) Hl[a] = st->H[a];
+  for (int a = 0; a < 6; ++a) {
+    Hl[a * 6 + a] += lambda;
+    nb[a] = -st->b[a];
+  }
+  double d[6], delta[16], xi[16];
+  ldlt6_solve(Hl, nb, d);               // LSQ:137-138
+  delta_from_d(d, delta);               // LSQ:140-142
+  isom_mul(delta, st->x0, xi);          // LSQ:144
+  for (int a = 0; a < 6; ++a) st->sd[a] = d[a];
+  for (int a = 0; a < 16; ++a) {
+    st->sdelta[a] = delta[a];
+    st->xi[a] = xi[a];
+  }
+  st->trial_active = 1;
+}
+
+__device__ void shard_end_iteration(PairState* __restrict__ st, const ApdConsts& cst) {  // the tail of lm_solve_kernel mode 0
+  const double inv_re = 1.0 / cst.rot_eps, inv_te = 1.0 / cst.trans_eps;
+  const int it = st->iter;
+  st->nr_iterations = it;  // LSQ:68
+  int done = 0, conv = 0;
+  if (!st->ok) {
+    done = 1;  // "lm not converged!!" LSQ:71-74
+    st->lm_failed = 1;
+  } else {
+    double delta[16];
+    for (int a = 0; a < 16; ++a) delta[a] = st->sdelta[a];
+    conv = is_converged(delta, inv_re, inv_te) ? 1 : 0;  // LSQ:75
+    if (conv) done = 1;
+  }
+  st->iter = it + 1;
+  if (it + 1 >= cst.max_iterations) done = 1;
+  st->converged = conv;
+  for (int a = 0; a < 12; ++a) st->Tf[a] = (float)st->x0[a];
+  st->trial_active = 0;
+  __threadfence();
+  st->done = done;
+}
+
+// after the all-reduce of red[28]: publish H, b, y0; Gauss-Newton: the whole step; LM: lambda initialisation and the first trial
+// pose.  mode 1 = linearize API (publish only).  grid 1, block 64 (one lane works: 6 x 6 algebra)
+__global__ __launch_bounds__(64) void shard_begin_kernel(const PairDesc* __restrict__ descs, const double* __restrict__ red, ApdConsts cst, int mode) {
+  const PairDesc& pd = descs[0];
+  PairState* __restrict__ st = pd.state;
+  if (st->done || threadIdx.x != 0) return;
+  int q = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) {
+      st->H[r * 6 + c] = red[q];
+      st->H[c * 6 + r] = red[q];
+      ++q;
+    }
+  for (int a = 0; a < 6; ++a) st->b[a] = red[21 + a];
+  st->y0 = red[27];
+  st->n_linearize += 1;
+  if (mode == 1) return;
+  st->ok = 0;
+  st->trial = 0;
+  st->trial_active = 0;
+  if (cst.optimizer == 0) {  // step_gn, LSQ:107-123
+    double Hl[36], nb[6], d[6], delta[16], xn[16], x0[16];
+    for (int a = 0; a < 36; ++a) Hl[a] = st->H[a];
+    for (int a = 0; a < 6; ++a) nb[a] = -st->b[a];
+    for (int a = 0; a < 16; ++a) x0[a] = st->x0[a];
+    ldlt6_solve(Hl, nb, d);
+    delta_from_d(d, delta);
+    isom_mul(delta, x0, xn);
+    for (int a = 0; a < 16; ++a) {
+      st->x0[a] = xn[a];
+      st->sdelta[a] = delta[a];
+    }
+    for (int a = 0; a < 36; ++a) st->Hfin[a] = st->H[a];
+    st->ok = 1;
+    shard_end_iteration(st, cst);
+    return;
+  }
+  if (st->lambda < 0.0) {  // LSQ:131-133
+    double mx = 0.0;
+    for (int a = 0; a < 6; ++a) mx = fmax(mx, fabs(st->H[a * 6 + a]));
+    st->lambda = cst.lm_init_lambda_factor * mx;
+  }
+  st->nu = 2.0;
+  shard_prepare_trial(st, st->lambda);
+}
+
+// this rank's part of compute_error at the trial pose (APD:310-346) -> ered[0] (then all-reduced in place).  mode 2: the
+// compute_error API (always evaluates at st->xi).  grid 1, block 1024
+__global__ __launch_bounds__(1024) void shard_trial_error_kernel(const PairDesc* __restrict__ descs, double* __restrict__ ered, ApdConsts cst, int mode) {
+  const PairDesc& pd = descs[0];
+  PairState* __restrict__ st = pd.state;
+  __shared__ double sred[16];
+  __shared__ double sxi[16];
+  if (mode != 2 && (st->done || !st->trial_active)) {  // wave-uniform: state is only written between launches
+    if (threadIdx.x == 0) ered[0] = 0.0;
+    return;
+  }
+  if (threadIdx.x < 16) sxi[threadIdx.x] = st->xi[threadIdx.x];
+  __syncthreads();
+  const double yi = block_error(pd, sxi, cst, sred);
+  if (threadIdx.x == 0) ered[0] = yi;
+}
+
+// after the all-reduce of the trial error: accept / reject (LSQ:146-170); on a rejection the next trial pose; with `last` (or once the
+// iteration is decided and no trial is pending) nothing is left but the end-of-iteration bookkeeping.  grid 1, block 64
+__global__ __launch_bounds__(64) void shard_trial_decide_kernel(const PairDesc* __restrict__ descs, const double* __restrict__ ered, ApdConsts cst, int last) {
+  const PairDesc& pd = descs[0];
+  PairState* __restrict__ st = pd.state;
+  if (st->done || threadIdx.x != 0) return;
+  if (st->trial_active) {
+    const double inv_re = 1.0 / cst.rot_eps, inv_te = 1.0 / cst.trans_eps;
+    const double yi = ered[0], lambda = st->lambda;
+    st->n_error += 1;
+    st->trial += 1;
+    double den = 0.0;
+    for (int a = 0; a < 6; ++a) den += st->sd[a] * (lambda * st->sd[a] - st->b[a]);
+    const double rho = (st->y0 - yi) / den;  // LSQ:146
+    if (rho < 0) {                             // LSQ:156-164
+      double delta[16];
+      for (int a = 0; a < 16; ++a) delta[a] = st->sdelta[a];
+      if (is_converged(delta, inv_re, inv_te)) {
+        st->ok = 1;
+        st->trial_active = 0;
+      } else {
+        st->lambda = st->nu * lambda;
+        st->nu = 2 * st->nu;
+        if (st->trial < cst.lm_max_iterations) shard_prepare_trial(st, st->lambda);
+        else st->trial_active = 0;
+      }
+    } else {
+      for (int a = 0; a < 16; ++a) st->x0[a] = st->xi[a];                   // LSQ:166
+      const double f = 1 - pow(2 * rho - 1, 3);
+      st->lambda = lambda * fmax(1.0 / 3.0, f);                            // LSQ:167
+      for (int a = 0; a < 36; ++a) st->Hfin[a] = st->H[a];                  // LSQ:168
+      st->ok = 1;
+      st->trial_active = 0;
+    }
+  }
+  if (last) shard_end_iteration(st, cst);
 }
 
 // final_transformation applied to the source (LSQ:79, pcl::transformPointCloud with a Matrix4f): float, Eigen product order

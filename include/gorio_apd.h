@@ -101,6 +101,14 @@ typedef struct {
 } gorio_apd_device_cloud;
 int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const gorio_apd_device_cloud* source, const gorio_apd_device_cloud* target);
 
+/* Batch extension (no counterpart in the reference, where every FastAPDGICP object builds its own kd-tree and covariances even when
+ * two objects are handed the same cloud pointer): h's target becomes THE SAME device-resident cloud as owner's current target --
+ * points, covariances and search index exist once per GPU however many handles register against them (BASELINE config C5: 512 scan
+ * pairs against one 1 M-point map: one upload, one index build and one k-NN pass instead of 512).  Both handles must live on one
+ * device.  Results are identical to giving h a private copy.  The link is by value of the moment: a later setInputTarget / clearTarget
+ * on either handle detaches that handle only.  gorio_apd_set_target_covariances on a shared target is seen by every sharer. */
+int gorio_apd_set_target_shared(gorio_apd_t* h, gorio_apd_t* owner);
+
 /* clearSource APD:101-105, clearTarget APD:107-112, swapSourceAndTarget APD:89-98 */
 int gorio_apd_clear_source(gorio_apd_t* h);
 int gorio_apd_clear_target(gorio_apd_t* h);
@@ -130,7 +138,9 @@ int gorio_apd_get_knn_indices(gorio_apd_t* h, int which, int* idx, int n_times_k
 int gorio_apd_align(gorio_apd_t* h, const float guess[16], float T_out[16], double* H_out, int* converged, int* nr_iterations, int* n_linearize);
 
 /* same for `count` independent handles advanced in lock-step on one device (one launch set per iteration).
- * guesses / T_out: count * 16 floats; H_out: count * 36 doubles or NULL; the int outputs: count entries or NULL. */
+ * guesses / T_out: count * 16 floats; H_out: count * 36 doubles or NULL; the int outputs: count entries or NULL.
+ * All handles must be distinct, live on one device and carry the same parameters (cl_weight_points is per handle); otherwise
+ * GORIO_ERR_INVALID.  Targets may be shared between the handles (gorio_apd_set_target_shared). */
 int gorio_apd_align_batch(gorio_apd_t** handles, int count, const float* guesses, float* T_out, double* H_out, int* converged, int* nr_iterations, int* n_linearize);
 
 /* linearize APD:224-307 (== evaluateCost LSQ:50-52 with a double pose): updates correspondences + Mahalanobis matrices at
@@ -156,6 +166,28 @@ int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out
  * points whose squared NN distance is < inlier_dist * inlier_dist.  The nodelet hard-codes max_correspondence_dist = 0.5 m there
  * (SMO:677); pass inlier_dist <= 0 to get exactly that.  Neither statistic depends on corr_dist_threshold. */
 int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double inlier_dist, double* score, double* inlier_fraction);
+
+/*
+ * Sharded-source mode -- "one large co-registration" (no counterpart in the reference, whose parallelism is one OpenMP
+ * team): several processes, one per GPU, each with a handle holding the SAME source and target clouds, form an RCCL communicator
+ * (RCCL = the "nccl" of ROCm, over xGMI inside a node).  From then on gorio_apd_align / _linearize / _compute_error on those handles
+ * are COLLECTIVE calls -- every rank makes them, in the same order with the same arguments.  Each rank searches and linearises only
+ * its contiguous part of the source (a spatially compact run of the search order); the covariances are estimated on the whole
+ * clouds by every rank, so they are exactly those of an unsharded run.  The only exchange is one in-place ncclAllReduce of 28
+ * doubles (H upper triangle, b, error) per linearisation and of 1 double per Levenberg-Marquardt trial, enqueued on the launch stream
+ * between the kernels; every rank then takes the same 6 x 6 step, so all ranks return the same pose without a broadcast and the
+ * result equals the unsharded one up to the rounding of the reordered fp64 sums.
+ *   rank 0:   gorio_comm_get_unique_id(id);  hand the 128 bytes to the other ranks by any means (MPI, torch.distributed, a file)
+ *   all:      gorio_apd_comm_init(h, world_size, rank, id);  ...  gorio_apd_comm_destroy(h);
+ * A handle with a communicator cannot be part of a gorio_apd_align_batch.  librccl is loaded on first use.
+ */
+int gorio_comm_get_unique_id(char id[128]);
+int gorio_apd_comm_init(gorio_apd_t* h, int world_size, int rank, const char id[128]);
+int gorio_apd_comm_destroy(gorio_apd_t* h);
+/* Test hook: the source partition of rank `rank` of `world_size` WITHOUT a communicator -- gorio_apd_linearize / _compute_error then
+ * return this rank's partial sums (a test adds them up itself; two such handles can live on one GPU, which two RCCL ranks cannot).
+ * world_size = 1 switches it off. */
+int gorio_apd_debug_set_shard(gorio_apd_t* h, int world_size, int rank);
 
 /* seconds spent inside device kernels of the last align / align_batch, by stage (HIP events on the launch stream):
  * [0] k-NN + covariance estimation, [1] correspondence search, [2] linearize, [3] LM/GN solve + error trials, [4] search-index build

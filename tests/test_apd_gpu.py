@@ -485,3 +485,51 @@ def test_knn_select_kernel_falls_back_on_massive_ties(gpu, gorio, oracle_apd):
         g = make(gorio, xyz, None, xyz, None, regularization=0, search=search)
         g.calculateCovariances()
         assert np.array_equal(g.getKnnIndices(0), idx_o), search
+
+
+def test_shared_target_equals_private_copies(gpu, gorio):
+    """gorio_apd_set_target_shared: N scans against ONE device-resident 100k map (one upload, one index, one k-NN pass) give bit for
+    bit what N handles with private copies of the map give; detaching one handle leaves the others on the shared map."""
+    tx, tl = synth.local_map(100000, seed=synth.BASE_SEED + 7)
+    scans = [synth.radar_scan(4000 + 100 * q, seed=200 + q) for q in range(6)]
+    kw = dict(corr_dist_threshold=2.0, search=1, transformation_epsilon=0.05)
+    priv = []
+    for sx, sl in scans:
+        g = make(gorio, sx, sl, tx, tl, **kw)
+        priv.append(g)
+    rp = gorio.align_batch(priv)
+    owner = gorio.ApdGicp(keep_knn_indices=1, **kw)
+    owner.setInputTarget(tx, tl)
+    shared = []
+    for sx, sl in scans:
+        g = gorio.ApdGicp(keep_knn_indices=1, **kw)
+        g.setInputTargetShared(owner)
+        g.setInputSource(sx, sl)
+        shared.append(g)
+    rs = gorio.align_batch(shared)
+    for a, b in zip(rp, rs):
+        assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["H"], b["H"]) and a["n_linearize"] == b["n_linearize"]
+    assert len(owner.getTargetCovariances()) == 100000  # the owner sees the covariances the batch computed once
+    assert np.array_equal(shared[3].getTargetCovariances(), priv[3].getTargetCovariances())
+    assert np.array_equal(shared[0].getKnnIndices(1)[:500], priv[0].getKnnIndices(1)[:500])
+    # detach: a new target on one sharer does not touch the others
+    shared[1].setInputTarget(tx[:50000], tl[:50000])
+    r1 = shared[1].align()
+    r2 = shared[2].align()
+    assert np.array_equal(r2["T"], rp[2]["T"]) and not np.array_equal(r1["T"], rp[1]["T"])
+    # single-handle calls on a shared target
+    e_s = shared[4].linearize(np.eye(4))
+    e_p = priv[4].linearize(np.eye(4))
+    assert e_s[0] == e_p[0] and np.array_equal(e_s[1], e_p[1])
+
+
+def test_batch_validation(gpu, gorio):
+    sx, sl, tx, tl, _ = synth.scan_pair(600, 700, seed=9)
+    a = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0)
+    b = make(gorio, sx, sl, tx, tl, corr_dist_threshold=1.0)
+    with pytest.raises(gorio.GorioError):
+        gorio.align_batch([a, b])  # different parameters in one lock-step batch
+    with pytest.raises(gorio.GorioError):
+        gorio.align_batch([a, a])  # the same handle twice
+    c = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, cl_weight_points=1200)
+    assert len(gorio.align_batch([a, c])) == 2  # cl_weight_points is per handle

@@ -131,3 +131,80 @@ def test_sharded_source_on_gpu_equals_single(gpu, gorio, pose_err):
     ro = one.align()
     te, re = pose_err(ro["T"], r["T"])
     assert te < 1e-5 and re < 1e-5 and r["n_linearize"] == ro["n_linearize"] and r["converged"] == ro["converged"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("search", [0, 1])
+def test_library_side_sharding_partitions_the_source(gpu, gorio, search):
+    """The source partition the RCCL mode uses (gorio_apd_debug_set_shard = the same bounds without the collectives): three "ranks" on
+    one GPU, each holding the WHOLE clouds, together match every source point exactly once, their partial H, b, error add up to the
+    unsharded ones, and the optimiser shell driving them (sum on the host instead of ncclAllReduce) reproduces the single-handle align."""
+    sx, sl, tx, tl, _ = synth.scan_pair(5000, 5200, seed=81)
+    kw = dict(corr_dist_threshold=2.0, search=search)
+    one = gorio.ApdGicp(transformation_epsilon=0.1, **kw)
+    one.setInputTarget(tx, tl)
+    one.setInputSource(sx, sl)
+    T = np.eye(4)
+    T[:3, 3] = [0.1, -0.05, 0.0]
+    e1, H1, b1 = one.linearize(T)
+    c1, _ = one.getCorrespondences()
+    ranks = []
+    for r in range(3):
+        g = gorio.ApdGicp(**kw)
+        g.setInputTarget(tx, tl)
+        g.setInputSource(sx, sl)
+        g.debugSetShard(3, r)
+        ranks.append(g)
+    parts = [g.linearize(T) for g in ranks]
+    corr = np.stack([g.getCorrespondences()[0] for g in ranks])
+    owned = (corr >= 0).sum(axis=0)
+    assert np.array_equal(owned > 0, c1 >= 0) and owned.max() == 1  # every matched point belongs to exactly one rank
+    assert np.array_equal(corr.max(axis=0), c1)
+    assert all((c >= 0).sum() > 500 for c in corr)  # a real three-way split
+    H, b, e = sum(p[1] for p in parts), sum(p[2] for p in parts), sum(p[0] for p in parts)
+    assert np.abs(H - H1).max() / np.abs(H1).max() < 1e-13 and np.abs(b - b1).max() / np.abs(b1).max() < 1e-12 and abs(e - e1) / e1 < 1e-13
+
+    class Ranks:
+        def linearize(self, T_):
+            ps = [g.linearize(T_) for g in ranks]
+            return sum(p[0] for p in ps), sum(p[1] for p in ps), sum(p[2] for p in ps)
+
+        def compute_error(self, T_):
+            return sum(g.compute_error(T_) for g in ranks)
+
+    r = sharded.align_sharded(Ranks(), transformation_epsilon=0.1)
+    ro = one.align()
+    assert r["n_linearize"] == ro["n_linearize"] and r["converged"] == ro["converged"]
+    assert np.allclose(r["T"], ro["T"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optimizer", [0, 1])
+def test_rccl_world1_communicator_runs_the_collective_path(gpu, gorio, optimizer):
+    """The RCCL path itself (librccl loaded at run time, ncclCommInitRank, in-place ncclAllReduce on the launch stream between the
+    kernels, the cut LM loop) with a communicator of ONE rank: the same pose, Hessian and iteration counts as the plain path, bit for bit
+    (the partial sums are added in the same order).  Two ranks cannot share one GPU under RCCL, so world > 1 runs only on a multi-GPU
+    node; the partition logic they would use is covered by the test above."""
+    sx, sl, tx, tl, _ = synth.scan_pair(6000, 6300, seed=82)
+    kw = dict(corr_dist_threshold=2.0, search=1, transformation_epsilon=0.01, optimizer=optimizer)
+    plain = gorio.ApdGicp(**kw)
+    plain.setInputTarget(tx, tl)
+    plain.setInputSource(sx, sl)
+    rp = plain.align()
+    g = gorio.ApdGicp(**kw)
+    g.commInit(1, 0, gorio.ApdGicp.commUniqueId())
+    g.setInputTarget(tx, tl)
+    g.setInputSource(sx, sl)
+    rc = g.align()
+    assert np.array_equal(rc["T"], rp["T"]) and np.array_equal(rc["H"], rp["H"])
+    assert rc["n_linearize"] == rp["n_linearize"] and rc["nr_iterations"] == rp["nr_iterations"] and rc["converged"] == rp["converged"]
+    T = rp["T"].astype(np.float64)
+    a, b_ = g.linearize(T), plain.linearize(T)
+    assert a[0] == b_[0] and np.array_equal(a[1], b_[1]) and np.array_equal(a[2], b_[2])
+    T2 = T.copy()
+    T2[0, 3] += 0.05
+    assert g.compute_error(T2) == plain.compute_error(T2)
+    with pytest.raises(gorio.GorioError):
+        gorio.align_batch([g, plain])  # a collective handle cannot ride in a lock-step batch
+    g.commDestroy()
+    assert np.array_equal(g.align()["T"], rp["T"])
