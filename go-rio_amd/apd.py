@@ -51,7 +51,7 @@ APD_SYMBOLS = [
     "gorio_apd_get_target_covariances", "gorio_apd_calculate_covariances", "gorio_apd_get_knn_indices", "gorio_apd_align",
     "gorio_apd_align_batch", "gorio_apd_linearize", "gorio_apd_compute_error", "gorio_apd_get_correspondences",
     "gorio_apd_get_mahalanobis", "gorio_apd_transform_source", "gorio_apd_fitness_score", "gorio_apd_set_profiling",
-    "gorio_apd_get_stage_times", "gorio_apd_set_target_shared", "gorio_comm_get_unique_id", "gorio_apd_comm_init", "gorio_apd_comm_destroy", "gorio_apd_debug_set_shard",
+    "gorio_apd_get_stage_times", "gorio_apd_set_target_shared", "gorio_comm_get_unique_id", "gorio_apd_comm_init", "gorio_apd_comm_destroy", "gorio_apd_debug_set_shard", "gorio_apd_set_target_submap", "gorio_apd_get_target_points",
 ]
 
 _lib = None
@@ -182,6 +182,32 @@ class ApdGicp:
         _check(self._h, self._lib.gorio_apd_set_target_shared(self._h, owner._h))
         self._n_tgt = owner._n_tgt
 
+    def setInputTargetSubmap(self, frames, rel_poses, voxel_leaf=0.0):  # noqa: N802
+        """gorio_apd_set_target_submap: frames = list of (xyz [n,3], label [n] or None), rel_poses = list of 4x4 (odom_i^-1 odom_newest)."""
+        n = len(frames)
+        arr = (Keyframe * n)()
+        keep = []
+        for i, ((xyz, lab), T) in enumerate(zip(frames, rel_poses)):
+            xyz, lab = self._cloud_args(xyz, lab)
+            buf = np.empty((xyz.shape[0], 4), np.float32)
+            buf[:, :3] = xyz
+            buf[:, 3] = 0.0 if lab is None else lab
+            Td = np.ascontiguousarray(T, np.float64)
+            keep += [buf, Td]
+            arr[i].xyz = buf.__array_interface__["data"][0]
+            arr[i].label = buf.__array_interface__["data"][0] + 12
+            arr[i].n, arr[i].point_stride_bytes = buf.shape[0], 16
+            arr[i].rel_pose = Td.__array_interface__["data"][0]
+        cnt = C.c_int(0)
+        _check(self._h, self._lib.gorio_apd_set_target_submap(self._h, arr, n, C.c_double(voxel_leaf), C.byref(cnt)))
+        self._n_tgt = cnt.value
+        return cnt.value
+
+    def getTargetPoints(self):  # noqa: N802
+        buf = np.empty((self._n_tgt, 4), np.float32)
+        _check(self._h, self._lib.gorio_apd_get_target_points(self._h, _p(buf, C.c_float), _p(buf[:, 3:], C.c_float), self._n_tgt, 16))
+        return buf[:, :3].copy(), buf[:, 3].copy()
+
     # ---- sharded-source mode (RCCL): see include/gorio_apd.h
     @staticmethod
     def commUniqueId():  # noqa: N802
@@ -311,6 +337,11 @@ class ApdGicp:
         c = (C.c_int * 8)()
         _check(self._h, self._lib.gorio_apd_get_stage_times(self._h, s, c))
         return list(s), list(c)
+
+
+class Keyframe(C.Structure):
+    """gorio_apd_keyframe (include/gorio_apd.h)."""
+    _fields_ = [("xyz", C.c_void_p), ("label", C.c_void_p), ("n", C.c_int), ("point_stride_bytes", C.c_int), ("rel_pose", C.c_void_p)]
 
 
 class DeviceCloud(C.Structure):

@@ -22,6 +22,7 @@
 #include "../../include/gorio_apd.h"
 #include "apd_kernels.hip"
 #include "apd_index.hip"
+#include "apd_submap.hip"
 
 using namespace gorio;
 
@@ -88,6 +89,19 @@ struct gorio_apd {
   IndexJob* d_ijobs = nullptr;
   int ijobs_cap = 0;
   double* d_fit = nullptr;
+  // scan-to-submap assembly scratch (gorio_apd_set_target_submap)
+  float4* d_sub_in = nullptr;
+  float4* d_sub_out = nullptr;
+  float4* d_sub_vox = nullptr;
+  size_t sub_cap = 0;
+  unsigned long long* d_sub_keys = nullptr;
+  size_t sub_keys_cap = 0;
+  int* d_sub_counts = nullptr;
+  size_t sub_counts_cap = 0;
+  SubmapFrame* d_sub_frames = nullptr;
+  int sub_frames_cap = 0;
+  unsigned int* d_sub_bb = nullptr;
+  IndexJob* d_sub_job = nullptr;
   // sharded-source mode (gorio_apd_comm_init): RCCL communicator over the ranks that share one source cloud
   ncclComm_t comm = nullptr;
   int comm_world = 1, comm_rank = 0;
@@ -852,6 +866,7 @@ void gorio_apd_destroy(gorio_apd_t* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->comm && rccl().ok) rccl().CommDestroy(h->comm);
   hipFree(h->d_red);
+  hipFree(h->d_sub_in); hipFree(h->d_sub_out); hipFree(h->d_sub_vox); hipFree(h->d_sub_keys); hipFree(h->d_sub_counts); hipFree(h->d_sub_frames); hipFree(h->d_sub_bb); hipFree(h->d_sub_job);
   h->src.reset();
   h->tgt.reset();
   hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
@@ -973,6 +988,151 @@ int gorio_apd_set_target_shared(gorio_apd_t* h, gorio_apd_t* owner) {
   if (!owner->tgt->present) return fail(h, GORIO_ERR_STATE, "set_target_shared: the owner has no input target");
   h->tgt = owner->tgt;  // points, covariances, search index: one copy on the device, alive until the last handle lets go of it
   h->corr_valid = false;
+  return GORIO_OK;
+}
+
+int gorio_apd_set_target_submap(gorio_apd_t* h, const gorio_apd_keyframe* frames, int count, double voxel_leaf, int* n_target) {
+  if (!h || !frames || count <= 0) return GORIO_ERR_INVALID;
+  HIP_TRY(h, hipSetDevice(h->device));
+  // ---- host staging: finite points of all frames, packed (x, y, z, label); pcl::PassThrough and pcl::VoxelGrid both skip non-finite points
+  std::vector<float4> stage;
+  std::vector<SubmapFrame> fr(count);
+  int max_frame = 0;
+  for (int k = 0; k < count; ++k) {
+    const gorio_apd_keyframe& f = frames[k];
+    if (f.n < 0 || (f.n > 0 && !f.xyz) || f.point_stride_bytes < 12 || (f.point_stride_bytes % 4) != 0 || !f.rel_pose) return fail(h, GORIO_ERR_INVALID, "set_target_submap: bad keyframe arguments");
+    fr[k].begin = (int)stage.size();
+    const int st = f.point_stride_bytes / 4;
+    for (int i = 0; i < f.n; ++i) {
+      const float* p = f.xyz + (size_t)i * st;
+      if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+      stage.push_back(make_float4(p[0], p[1], p[2], f.label ? f.label[(size_t)i * st] : 0.0f));
+    }
+    fr[k].end = (int)stage.size();
+    for (int q = 0; q < 12; ++q) fr[k].T[q] = f.rel_pose[q];
+    max_frame = std::max(max_frame, fr[k].end - fr[k].begin);
+  }
+  const int m = (int)stage.size();
+  if (m <= 0) return fail(h, GORIO_ERR_INVALID, "set_target_submap: no finite point in any keyframe");
+  if ((size_t)m > h->sub_cap) {
+    hipFree(h->d_sub_in); hipFree(h->d_sub_out); hipFree(h->d_sub_vox);
+    h->d_sub_in = h->d_sub_out = h->d_sub_vox = nullptr;
+    h->sub_cap = 0;
+    const size_t cap = (size_t)m + (size_t)m / 8;
+    HIP_TRY(h, hipMalloc(&h->d_sub_in, sizeof(float4) * cap));
+    HIP_TRY(h, hipMalloc(&h->d_sub_out, sizeof(float4) * cap));
+    HIP_TRY(h, hipMalloc(&h->d_sub_vox, sizeof(float4) * cap));
+    h->sub_cap = cap;
+  }
+  if (count > h->sub_frames_cap) {
+    hipFree(h->d_sub_frames);
+    h->d_sub_frames = nullptr;
+    HIP_TRY(h, hipMalloc(&h->d_sub_frames, sizeof(SubmapFrame) * count));
+    h->sub_frames_cap = count;
+  }
+  if (!h->d_sub_bb) HIP_TRY(h, hipMalloc(&h->d_sub_bb, sizeof(unsigned int) * 8));
+  if (!h->d_sub_job) HIP_TRY(h, hipMalloc(&h->d_sub_job, sizeof(IndexJob)));
+  HIP_TRY(h, hipMemcpyAsync(h->d_sub_in, stage.data(), sizeof(float4) * m, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_sub_frames, fr.data(), sizeof(SubmapFrame) * count, hipMemcpyHostToDevice, h->stream));
+  submap_transform_kernel<<<dim3((max_frame + 255) / 256, count), 256, 0, h->stream>>>(h->d_sub_in, h->d_sub_frames, h->d_sub_out);
+  HIP_TRY(h, hipGetLastError());
+  const float4* result = h->d_sub_out;
+  int n_out = m;
+  if (voxel_leaf > 0.0) {  // pcl::VoxelGrid (SMO:145-149)
+    unsigned int bb[6];
+    vox_bbox_init_kernel<<<1, 64, 0, h->stream>>>(h->d_sub_bb);
+    vox_bbox_kernel<<<std::min(256, (m + 255) / 256), 256, 0, h->stream>>>(h->d_sub_out, m, h->d_sub_bb);
+    HIP_TRY(h, hipMemcpyAsync(bb, h->d_sub_bb, sizeof(bb), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // also covers the pageable staging vectors above
+    auto ord2f_host = [](unsigned int o) {
+      const unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+      float f;
+      std::memcpy(&f, &u, 4);
+      return f;
+    };
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) { mn[a] = ord2f_host(bb[a]); mx[a] = ord2f_host(bb[3 + a]); }
+    VoxGrid g;
+    g.inv = 1.0f / (float)voxel_leaf;
+    const long long dx = (long long)((mx[0] - mn[0]) * g.inv) + 1, dy = (long long)((mx[1] - mn[1]) * g.inv) + 1, dz = (long long)((mx[2] - mn[2]) * g.inv) + 1;
+    if (dx * dy * dz <= (long long)INT_MAX) {  // otherwise: "Leaf size is too small for the input dataset" -> PCL returns the input unchanged
+      int div_b[3];
+      for (int a = 0; a < 3; ++a) {
+        g.min_b[a] = (int)std::floor(mn[a] * g.inv);
+        div_b[a] = (int)std::floor(mx[a] * g.inv) - g.min_b[a] + 1;
+      }
+      g.div0 = div_b[0];
+      g.div01 = div_b[0] * div_b[1];
+      int npow2 = kSortTile;
+      while (npow2 < m) npow2 <<= 1;
+      if ((size_t)npow2 > h->sub_keys_cap) {
+        hipFree(h->d_sub_keys);
+        h->d_sub_keys = nullptr;
+        h->sub_keys_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_sub_keys, sizeof(unsigned long long) * npow2));
+        h->sub_keys_cap = npow2;
+      }
+      const int nblocks = (m + 255) / 256;
+      if ((size_t)nblocks + 1 > h->sub_counts_cap) {
+        hipFree(h->d_sub_counts);
+        h->d_sub_counts = nullptr;
+        h->sub_counts_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_sub_counts, sizeof(int) * (nblocks + 1 + nblocks / 8)));
+        h->sub_counts_cap = nblocks + 1 + nblocks / 8;
+      }
+      IndexJob job;
+      std::memset(&job, 0, sizeof(job));
+      job.n = m;
+      job.npow2 = npow2;
+      job.keys = h->d_sub_keys;
+      HIP_TRY(h, hipMemcpyAsync(h->d_sub_job, &job, sizeof(job), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));  // `job` is a stack object
+      vox_key_kernel<<<(npow2 + 255) / 256, 256, 0, h->stream>>>(h->d_sub_out, m, npow2, g, h->d_sub_keys);
+      const IndexJob* dj = h->d_sub_job;
+      bitonic_tile_sort_kernel<<<dim3(npow2 / kSortTile, 1), 1024, 0, h->stream>>>(dj);
+      for (int k = 2 * kSortTile; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j >= kSortTile; j >>= 1) bitonic_global_kernel<<<dim3((npow2 / 2 + 255) / 256, 1), 256, 0, h->stream>>>(dj, k, j);
+        bitonic_tile_merge_kernel<<<dim3(npow2 / kSortTile, 1), 1024, 0, h->stream>>>(dj, k);
+      }
+      vox_count_kernel<<<nblocks, 256, 0, h->stream>>>(h->d_sub_keys, m, h->d_sub_counts);
+      vox_scan_kernel<<<1, 1024, 0, h->stream>>>(h->d_sub_counts, nblocks);
+      vox_centroid_kernel<<<nblocks, 256, 0, h->stream>>>(h->d_sub_keys, h->d_sub_out, m, h->d_sub_counts, h->d_sub_vox);
+      HIP_TRY(h, hipGetLastError());
+      HIP_TRY(h, hipMemcpyAsync(&n_out, h->d_sub_counts + nblocks, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      result = h->d_sub_vox;
+    }
+  }
+  make_private(h, h->tgt);
+  DevCloud& c = *h->tgt;
+  int rc = ensure_cloud(h, c, n_out);
+  if (rc) return rc;
+  submap_store_kernel<<<(c.n_pad + 255) / 256, 256, 0, h->stream>>>(result, n_out, c.n_pad, c.x, c.y, c.z, c.label, c.p4);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // the staging vectors die with this call
+  c.present = true;
+  c.cov_count = 0;
+  c.idx_valid = false;
+  c.knn_valid = false;
+  h->corr_valid = false;
+  if (n_target) *n_target = n_out;
+  return GORIO_OK;
+}
+
+int gorio_apd_get_target_points(gorio_apd_t* h, float* xyz_out, float* label_out, int n, int point_stride_bytes) {
+  if (!h || !xyz_out) return GORIO_ERR_INVALID;
+  if (!h->tgt->present || n != h->tgt->n) return fail(h, GORIO_ERR_STATE, "get_target_points: no matching target cloud");
+  if (point_stride_bytes < 12 || point_stride_bytes % 4) return fail(h, GORIO_ERR_INVALID, "get_target_points: bad stride");
+  HIP_TRY(h, hipSetDevice(h->device));
+  std::vector<float4> tmp((size_t)n);
+  HIP_TRY(h, hipMemcpyAsync(tmp.data(), h->tgt->p4, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const int st = point_stride_bytes / 4;
+  for (int i = 0; i < n; ++i) {
+    float* o = xyz_out + (size_t)i * st;
+    o[0] = tmp[i].x; o[1] = tmp[i].y; o[2] = tmp[i].z;
+    if (label_out) label_out[(size_t)i * st] = tmp[i].w;
+  }
   return GORIO_OK;
 }
 

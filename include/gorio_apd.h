@@ -109,6 +109,28 @@ int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const go
  * on either handle detaches that handle only.  gorio_apd_set_target_covariances on a shared target is seen by every sharer. */
 int gorio_apd_set_target_shared(gorio_apd_t* h, gorio_apd_t* owner);
 
+/*
+ * Scan-to-submap target assembly (scan_matching_odometry_nodelet.cpp:602-618, "SMO"): what the nodelet does on the CPU before
+ * registration_s2m->setInputTarget -- every keyframe cloud moved by rel_pose = odom_i^-1 * odom_newest (pcl::transformPointCloud with
+ * a double matrix, SMO:606-608), concatenated in the order given (SMO:609), passed through downsample() (SMO:611, 405-415) -- here on
+ * the GPU, straight into the handle's device-resident target (the covariances of the new target are stale, as after setInputTarget).
+ *   voxel_leaf <= 0   downsample_method NONE of the shipped launch files: pcl::PassThrough, i.e. only non-finite points are dropped
+ *   voxel_leaf  > 0   pcl::VoxelGrid with that leaf size, downsample_all_data (SMO:145-149): one centroid per occupied voxel, in
+ *                     ascending voxel index; the label of a voxel is the NORMALISED sum of its points' labels (sign), as
+ *                     AccumulatorNormal leaves normal_x
+ * n_target (may be NULL) receives the number of points of the assembled target; gorio_apd_get_target_points reads them back (xyz and
+ * label strided like set_target's input; label_out may be NULL).
+ */
+typedef struct {
+  const float* xyz;        /* first x of the keyframe cloud (host) */
+  const float* label;      /* first normal_x, same stride, or NULL */
+  int n;
+  int point_stride_bytes;  /* 48 for pcl::PointXYZINormal */
+  const double* rel_pose;  /* 16 doubles, ROW-major 4x4 */
+} gorio_apd_keyframe;
+int gorio_apd_set_target_submap(gorio_apd_t* h, const gorio_apd_keyframe* frames, int count, double voxel_leaf, int* n_target);
+int gorio_apd_get_target_points(gorio_apd_t* h, float* xyz_out, float* label_out, int n, int point_stride_bytes);
+
 /* clearSource APD:101-105, clearTarget APD:107-112, swapSourceAndTarget APD:89-98 */
 int gorio_apd_clear_source(gorio_apd_t* h);
 int gorio_apd_clear_target(gorio_apd_t* h);

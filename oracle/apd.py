@@ -198,3 +198,20 @@ def align(guess, src_xyz, src_label, tgt_xyz, tgt_label, src_cov, tgt_cov, param
         out["trace"] = trace[: cnt.n_linearize]
         out["trace_corr"] = trace_corr[: cnt.n_linearize]
     return out
+
+
+def submap_assemble(frames, rel_poses, voxel_leaf=0.0):
+    """SMO:602-618: transform the keyframe clouds by rel_poses (4x4 double), concatenate, downsample (voxel_leaf <= 0: the launch
+    files' NONE = PassThrough).  frames: list of (xyz [n,3] float32, label [n] float32).  Returns (xyz, label)."""
+    xyz = _f32(np.concatenate([f[0] for f in frames]))
+    lab = _f32(np.concatenate([f[1] for f in frames]))
+    cnt = np.ascontiguousarray([f[0].shape[0] for f in frames], np.int32)
+    T = _f64(np.stack([np.asarray(t, np.float64) for t in rel_poses]))
+    cap = xyz.shape[0]
+    ox = np.empty((max(cap, 1), 3), np.float32)
+    ol = np.empty(max(cap, 1), np.float32)
+    n = lib().apdo_submap_assemble(_p(xyz, C.c_float), _p(lab, C.c_float), _p(cnt, C.c_int), _p(T, C.c_double), len(frames), C.c_double(voxel_leaf),
+                                   _p(ox, C.c_float), _p(ol, C.c_float), cap)
+    if n < 0:
+        raise RuntimeError("apdo_submap_assemble failed")
+    return ox[:n].copy(), ol[:n].copy()

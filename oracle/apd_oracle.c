@@ -985,3 +985,129 @@ void apdo_transform_point_f(const double* T, const float* p, float* q) {
   for (int i = 0; i < 16; i++) Tf[i] = (float)T[i];
   transform_point_f(Tf, p[0], p[1], p[2], q);
 }
+
+/* ------------------------------------------------------------------------------------------------ scan-to-submap target assembly
+ *
+ * SMO = /root/reference/4DRadarSLAM/apps/scan_matching_odometry_nodelet.cpp.  SMO:602-618: for the last max_submap_frames - 1
+ * keyframes before the newest, rel_pose = odom_i^-1 * odom_newest (double), pcl::transformPointCloud(*cloud_i, out, rel_pose),
+ * submap += out; then downsample(submap) (SMO:405-415) and setInputTarget.  The caller computes the rel_pose matrices.
+ *
+ * Third-party behaviour restated (PCL 1.10, NOT under /root/reference: "parity unpinned"):
+ *  - pcl::transformPointCloud with a double matrix (common/impl/transforms.hpp, pcl::detail::Transformer<double>::se3):
+ *        out_r = (float)(tf(r,0) * x + tf(r,1) * y + tf(r,2) * z + tf(r,3))   in double, left to right; all other fields copied.
+ *  - downsample_method NONE (launch/ntu_loop3.launch:82) = pcl::PassThrough without a filter field: drops non-finite points.
+ *  - downsample_method VOXELGRID = pcl::VoxelGrid<PointXYZINormal> (filters/impl/voxel_grid.hpp), downsample_all_data = true:
+ *        float inverse leaf = 1 / leaf; min_b = floor(min * inv), div_b = max_b - min_b + 1; voxel index of a point
+ *        idx = (floor(x inv) - min_b.x) + (floor(y inv) - min_b.y) div_b.x + (floor(z inv) - min_b.z) div_b.x div_b.y;
+ *        points sorted by idx, one output point per occupied voxel in ascending idx order: xyz = float sum / count
+ *        (AccumulatorXYZ), the "normal" (normal_x = cluster label here, normal_y = normal_z = 0) summed and NORMALISED
+ *        (AccumulatorNormal: Eigen 3.3 normalize() leaves a zero vector alone) -- so a voxel's label becomes sign(sum).
+ *        PCL orders the points of one voxel by an unstable std::sort; here they are added in ascending input order.
+ *        When the voxel count overflows int32 PCL warns and returns the input unchanged; so does this.
+ * Returns the number of output points (<= cap), or -1 when cap is too small.
+ */
+typedef struct {
+  int64_t idx;
+  int point;
+} apdo_vox_ref;
+
+static int vox_cmp(const void* a, const void* b) {
+  const apdo_vox_ref* x = (const apdo_vox_ref*)a;
+  const apdo_vox_ref* y = (const apdo_vox_ref*)b;
+  if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+  return x->point < y->point ? -1 : (x->point > y->point ? 1 : 0);
+}
+
+int apdo_submap_assemble(const float* xyz /* all frames, packed n x 3 */, const float* label, const int* frame_n, const double* rel_pose /* count x 16, row-major */,
+                         int count, double voxel_leaf, float* out_xyz, float* out_label, int cap) {
+  int total = 0;
+  for (int k = 0; k < count; k++) total += frame_n[k];
+  float* tx = (float*)malloc(sizeof(float) * 3 * (size_t)(total > 0 ? total : 1));
+  float* tl = (float*)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1));
+  int m = 0, off = 0;
+  for (int k = 0; k < count; k++) {
+    const double* T = rel_pose + (size_t)k * 16;
+    for (int i = 0; i < frame_n[k]; i++) {
+      const float* p = xyz + 3 * (size_t)(off + i);
+      if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue; /* PassThrough / VoxelGrid both skip non-finite points */
+      const double x = (double)p[0], y = (double)p[1], z = (double)p[2];
+      tx[3 * (size_t)m + 0] = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+      tx[3 * (size_t)m + 1] = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+      tx[3 * (size_t)m + 2] = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+      tl[m] = label ? label[off + i] : 0.0f;
+      m++;
+    }
+    off += frame_n[k];
+  }
+  int n_out = -1;
+  int passthrough = !(voxel_leaf > 0.0);
+  apdo_vox_ref* refs = NULL;
+  if (!passthrough && m > 0) {
+    const float inv = 1.0f / (float)voxel_leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = 0; i < m; i++)
+      for (int a = 0; a < 3; a++) {
+        if (tx[3 * (size_t)i + a] < mn[a]) mn[a] = tx[3 * (size_t)i + a];
+        if (tx[3 * (size_t)i + a] > mx[a]) mx[a] = tx[3 * (size_t)i + a];
+      }
+    const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT32_MAX) {
+      passthrough = 1; /* "Leaf size is too small for the input dataset. Integer indices would overflow." -> output = input */
+    } else {
+      int min_b[3], max_b[3], div_b[3];
+      for (int a = 0; a < 3; a++) {
+        min_b[a] = (int)floorf(mn[a] * inv);
+        max_b[a] = (int)floorf(mx[a] * inv);
+        div_b[a] = max_b[a] - min_b[a] + 1;
+      }
+      refs = (apdo_vox_ref*)malloc(sizeof(apdo_vox_ref) * (size_t)m);
+      for (int i = 0; i < m; i++) {
+        const int i0 = (int)floorf(tx[3 * (size_t)i] * inv) - min_b[0];
+        const int i1 = (int)floorf(tx[3 * (size_t)i + 1] * inv) - min_b[1];
+        const int i2 = (int)floorf(tx[3 * (size_t)i + 2] * inv) - min_b[2];
+        refs[i].idx = (int64_t)i0 + (int64_t)i1 * div_b[0] + (int64_t)i2 * div_b[0] * div_b[1];
+        refs[i].point = i;
+      }
+      qsort(refs, (size_t)m, sizeof(apdo_vox_ref), vox_cmp);
+      n_out = 0;
+      int i = 0;
+      while (i < m) {
+        int j = i;
+        float sx = 0.f, sy = 0.f, sz = 0.f, sn = 0.f;
+        while (j < m && refs[j].idx == refs[i].idx) {
+          const int q = refs[j].point;
+          sx += tx[3 * (size_t)q];
+          sy += tx[3 * (size_t)q + 1];
+          sz += tx[3 * (size_t)q + 2];
+          sn += tl[q];
+          j++;
+        }
+        if (n_out >= cap) {
+          n_out = -1;
+          break;
+        }
+        const float cnt = (float)(j - i);
+        out_xyz[3 * (size_t)n_out] = sx / cnt;
+        out_xyz[3 * (size_t)n_out + 1] = sy / cnt;
+        out_xyz[3 * (size_t)n_out + 2] = sz / cnt;
+        const float z2 = sn * sn;
+        out_label[n_out] = z2 > 0.f ? sn / sqrtf(z2) : sn;
+        n_out++;
+        i = j;
+      }
+    }
+  }
+  if (passthrough || m == 0) {
+    if (m > cap) {
+      n_out = -1;
+    } else {
+      memcpy(out_xyz, tx, sizeof(float) * 3 * (size_t)m);
+      memcpy(out_label, tl, sizeof(float) * (size_t)m);
+      n_out = m;
+    }
+  }
+  free(refs);
+  free(tx);
+  free(tl);
+  return n_out;
+}
