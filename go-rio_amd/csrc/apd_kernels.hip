@@ -367,17 +367,29 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const PairDesc* __restri
   const scalar_fp tx = as_scalar(pd.tgt.x);
   const scalar_fp ty = as_scalar(pd.tgt.y);
   const scalar_fp tz = as_scalar(pd.tgt.z);
+  // v_cmp / v_cndmask / v_min issue at HALF the rate of v_sub / v_mul / v_add on gfx950 (tools/valu_rate.hip): a compare and two selects
+  // per candidate cost as much as six of the eight distance instructions.  So the loop only tracks the minimum of every 16-candidate
+  // chunk (a v_min3 tree: half an instruction per candidate) and which chunk held the best one; the index inside that chunk is
+  // recovered once at the end.  Strict '<' between chunks and "first equal" inside the chunk keep ties on the LOWEST index.
   float best = INFINITY;
-  int bj = 0x7fffffff;
+  int bc = 0x7fffffff;  // first candidate of the chunk that holds the best distance
   for (int j = j0; j < j1; j += 16) {
     float d[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) d[u] = sqdist3(qx, qy, qz, tx[j + u], ty[j + u], tz[j + u]);
+    const float m0 = fminf(fminf(d[0], d[1]), d[2]), m1 = fminf(fminf(d[3], d[4]), d[5]), m2 = fminf(fminf(d[6], d[7]), d[8]);
+    const float m3 = fminf(fminf(d[9], d[10]), d[11]), m4 = fminf(fminf(d[12], d[13]), d[14]);
+    const float m = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15]));
+    const bool lt = m < best;
+    best = lt ? m : best;
+    bc = lt ? j : bc;
+  }
+  int bj = 0x7fffffff;
+  if (bc != 0x7fffffff) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const bool lt = d[u] < best;
-      best = lt ? d[u] : best;
-      bj = lt ? j + u : bj;
+    for (int u = 15; u >= 0; --u) {  // descending, so the lowest matching index is the one that stays
+      const float d = sqdist3(qx, qy, qz, pd.tgt.x[bc + u], pd.tgt.y[bc + u], pd.tgt.z[bc + u]);
+      bj = d == best ? bc + u : bj;
     }
   }
   if (i < n && bj != 0x7fffffff) {

@@ -160,6 +160,35 @@ public:
     const std::size_t n = input_ ? input_->size() : 0;
     return n ? static_cast<float>(std::llround(frac * static_cast<double>(n))) / n : 0.0f;
   }
+  // Scan-to-submap target assembly on the GPU (extra; replaces the CPU loop of scan_matching_odometry_nodelet.cpp:602-612): keyframe
+  // clouds moved by their relative poses, concatenated, downsampled (voxel_leaf <= 0: the launch files' NONE), set as the target.  The
+  // assembled cloud is also returned as a pcl cloud and kept as target_, because pcl::Registration::align() insists on one.
+  PointCloudTargetConstPtr setInputTargetSubmap(const std::vector<PointCloudTargetConstPtr>& clouds,
+                                                const std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::Matrix4d>>& rel_poses, double voxel_leaf = 0.0) {
+    if (clouds.empty() || clouds.size() != rel_poses.size()) throw std::invalid_argument("setInputTargetSubmap: one relative pose per keyframe cloud");
+    std::vector<gorio_apd_keyframe> fr(clouds.size());
+    std::vector<double> poses(clouds.size() * 16);
+    for (std::size_t k = 0; k < clouds.size(); ++k) {
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) poses[k * 16 + r * 4 + c] = rel_poses[k](r, c);
+      const bool any = clouds[k] && !clouds[k]->points.empty();
+      fr[k].xyz = any ? clouds[k]->points[0].data : nullptr;
+      fr[k].label = any ? &clouds[k]->points[0].normal_x : nullptr;
+      fr[k].n = any ? static_cast<int>(clouds[k]->size()) : 0;
+      fr[k].point_stride_bytes = static_cast<int>(sizeof(PointTarget));
+      fr[k].rel_pose = &poses[k * 16];
+    }
+    int n = 0;
+    check(gorio_apd_set_target_submap(handle_, fr.data(), static_cast<int>(fr.size()), voxel_leaf, &n));
+    PointCloudTargetPtr out(new PointCloudTarget());
+    out->resize(n);
+    if (n > 0) check(gorio_apd_get_target_points(handle_, out->points[0].data, &out->points[0].normal_x, n, static_cast<int>(sizeof(PointTarget))));
+    for (auto& p : out->points) p.data[3] = 1.0f;
+    pcl::Registration<PointSource, PointTarget, Scalar>::setInputTarget(out);  // bookkeeping only: the device already holds it
+    target_covs_.clear();
+    target_covs_fresh_ = false;
+    return out;
+  }
   // extras (not in the reference): correspondences of the last linearisation, device handle
   void getCorrespondences(std::vector<int>& corr, std::vector<float>& sq_dist) {
     const int n = static_cast<int>(input_->size());
