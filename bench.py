@@ -298,13 +298,24 @@ def load_counters():
 
 
 def kernel_entry(counters, kernel, workload):
-    return counters.get("kernels", {}).get(f"{kernel}:{workload}")
+    """Counters of one kernel, or the sums over the kernels of a stage written as "a + b" (the k-NN stage is two launches)."""
+    parts = [k.strip() for k in kernel.split(" + ")]
+    es = [counters.get("kernels", {}).get(f"{k}:{workload}") for k in parts]
+    if any(e is None for e in es):
+        return None
+    if len(es) == 1:
+        return es[0]
+    out = {}
+    for key in ("valu_issue_slots", "SQ_INSTS_VALU", "hbm_bytes", "mfma_flops", "fetch_bytes", "write_bytes"):
+        if all(key in e for e in es):
+            out[key] = sum(e[key] for e in es)
+    return out
 
 
 def valu_roofline(kernel, entry, avg_s, extra_note=""):
-    """Issue-slot roofline of a vector-ALU bound kernel from EXECUTED instructions: every wave64 VALU instruction occupies one of the
-    chip's 1024 x 2.4e9 / 2 issue slots per second (fp64 ones two: `valu_issue_cycles` from the SQ counters accounts for that), and
-    an fp32 FMA in every slot is the 157.3 TFLOP/s peak.  achieved = slots used per second expressed in the same unit."""
+    """Issue-slot roofline of a vector-ALU bound kernel from EXECUTED instructions: the chip has 1024 x 2.4e9 / 2 fp32 issue slots
+    per second (an fp32 FMA in every one is the 157.3 TFLOP/s peak); a wave64 instruction of the slow classes (fp64, compares,
+    selects, min / max, 64-bit integer) takes two of them.  achieved = slots used per second expressed in the same unit."""
     r = {"bound": "valu", "kernel": kernel, "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
          "avg_launch_ms": 1e3 * avg_s}
     if entry and avg_s > 0:
@@ -319,8 +330,9 @@ def valu_roofline(kernel, entry, avg_s, extra_note=""):
             r["traffic"] = hb
             r["hbm_gbs"] = hb / avg_s / 1e9
             r["hbm_frac"] = hb / avg_s / 1e9 / PEAK_HBM_GBS
-    r["note"] = ("vector-ALU issue bound: achieved = executed wave64 VALU issue slots per launch (SQ_INSTS_VALU, fp64 counted twice; profiles/kernel_counters.json) x 64 lanes x 2 "
-                 "flop / live launch time; peak = 157.3 TFLOP/s (an fp32 FMA in every slot), so frac is the share of VALU issue slots the kernel fills" + extra_note)
+    r["note"] = ("vector-ALU issue bound: achieved = EXECUTED wave64 VALU issue slots per launch (SQ instruction counters priced at the measured gfx950 issue rates: fp32 add/mul/fma and "
+                 "int32 = 1 slot of 2 cycles, fp64 / compare / select / min / max / 64-bit = 2 slots; profiles/kernel_counters.json) x 64 lanes x 2 flop / live launch time; "
+                 "peak = 157.3 TFLOP/s (an fp32 FMA in every slot), so frac is the share of the chip's VALU issue time the kernel fills" + extra_note)
     return r
 
 
@@ -328,7 +340,7 @@ def report(args, world, n_pairs, n, m, resident, units, wins, dt, stage_s, stage
     wl = args.workload
     counters = load_counters()
     steps = args.steps
-    knn_name = "knn_pruned_kernel<20>" if args.search == "pruned" else "knn_partial_kernel<20>"
+    knn_name = "knn_kth_kernel<20> + knn_collect_kernel<20>" if args.search == "pruned" else "knn_partial_kernel<20> + cov_finalize_kernel<20>"
     nn_name = "nn_search_pruned_kernel" if args.search == "pruned" else "nn_search_kernel"
     avg = lambda s, c: s / max(c, 1)  # noqa: E731
     # per-stage device time of the timed region (HIP events on the launch streams), per step

@@ -5,9 +5,10 @@
 
 For every kernel of the library it averages each counter over the launches of the run (rocprofv3 sums a counter over the chip per
 dispatch), writes the per-launch averages, and derives:
-  valu_issue_slots  SQ_INSTS_VALU + the fp64 instructions once more (a wave64 fp64 VALU instruction holds its SIMD 4 cycles, an fp32 /
-                    integer one 2: MI355X_MICROARCH.md "cycle constants"; matrix instructions are not VALU issue slots and are removed)
-  valu_busy         4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)   (utilisation under the profiler's clocks)
+  valu_issue_slots  VALU issue time in units of 2 cycles (= one fp32 FMA slot): fp32 add / mul / fma and int32 instructions count 1,
+                    every other VALU instruction (fp64, compare, select, min / max / med3, 64-bit integer) counts 2 -- the rates
+                    tools/valu_rate.hip measures on gfx950; matrix instructions are not VALU issue slots and are removed
+  valu_busy         2 cycles x valu_issue_slots / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)   (utilisation under the profiler's clocks)
   mfma_flops        512 x SQ_INSTS_VALU_MFMA_MOPS_F64
   hbm_bytes         FETCH_SIZE x 1024 (x 2 only for the kernels listed in WIDE_STREAMS, the guide's gfx950 correction applies to wide
                     coalesced streams) + WRITE_SIZE x 1024
@@ -79,11 +80,21 @@ def main():
         e = dict(c)
         e["launches_in_profile"] = launches[k]
         if "SQ_INSTS_VALU" in c:
-            f64 = sum(c.get(x, 0.0) for x in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
             mfma = c.get("SQ_INSTS_MFMA", 0.0)
-            e["valu_issue_slots"] = c["SQ_INSTS_VALU"] - mfma + f64
-        if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
-            e["valu_busy"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+            valu = c["SQ_INSTS_VALU"] - mfma
+            if "SQ_INSTS_VALU_ADD_F32" in c:
+                # measured issue rates on gfx950 (tools/valu_rate.hip): fp32 add / sub / mul / fma and 32-bit integer / logic instructions
+                # hold a SIMD for 2 cycles per wave64 instruction; fp64 arithmetic, compares, selects, min / max / med3 and 64-bit
+                # integer instructions for 4.  The SQ counters classify the first group; everything else is priced at the slow rate.
+                fast = sum(c.get(x, 0.0) for x in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_INT32"))
+                fast = min(fast, valu)
+                e["valu_fast_instructions"], e["valu_slow_instructions"] = fast, valu - fast
+                e["valu_issue_slots"] = fast + 2.0 * (valu - fast)  # in units of 2 cycles: one fp32-FMA issue slot
+            else:
+                f64 = sum(c.get(x, 0.0) for x in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+                e["valu_issue_slots"] = valu + f64
+        if "valu_issue_slots" in e and c.get("GRBM_GUI_ACTIVE"):
+            e["valu_busy"] = 2.0 * e["valu_issue_slots"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0)  # under the profiler's own clocks
         if "SQ_INSTS_VALU_MFMA_MOPS_F64" in c:
             e["mfma_flops"] = 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]
         if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
