@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -31,7 +32,9 @@ struct Ctx {  // per-thread, per-device cached buffers
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // the state-correlation chain runs here, beside the two GP fits (a helper thread in the reference, preint.h:939-1064)
-  hipEvent_t ev_jac = nullptr, ev_corr = nullptr;
+  hipEvent_t ev_jac = nullptr, ev_corr = nullptr, ev_up = nullptr;
+  struct Group { hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev_jac = nullptr, ev_corr = nullptr, ev_done = nullptr; };
+  std::vector<Group> groups;  // group 0 = (stream, stream2)
   double* ws = nullptr;
   size_t ws_cap = 0;
   UgpmWin* d_wins = nullptr;
@@ -234,6 +237,12 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   UHIP(hipSetDevice(device));
   Ctx& c = g_ctx;
   if (c.device != device) {
+    for (size_t g = 1; g < c.groups.size(); ++g) {
+      hipStreamDestroy(c.groups[g].s); hipStreamDestroy(c.groups[g].s2);
+      hipEventDestroy(c.groups[g].ev_jac); hipEventDestroy(c.groups[g].ev_corr);
+    }
+    for (auto& g : c.groups) hipEventDestroy(g.ev_done);
+    if (c.ev_up) hipEventDestroy(c.ev_up);
     if (c.stream) hipStreamDestroy(c.stream);
     if (c.stream2) hipStreamDestroy(c.stream2);
     if (c.ev_jac) hipEventDestroy(c.ev_jac);
@@ -508,83 +517,147 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   const int max_G = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.is_lpm ? 2 : h.G); return m; }();
   const int max_V = [&] { int m = 2; for (auto& h : hw) m = std::max(m, h.is_lpm ? 2 : h.V); return m; }();
   if (max_S > 0) {
+    // The windows are independent and nearly every kernel below is a chain of short, latency-bound launches with one (or a few)
+    // workgroups per window, so the batch CAN be cut into groups that advance on their own pairs of streams (main + correlation
+    // chain).  Measured on the C4 batch (64 windows, profiles/r02/ugpm_groups.txt): 1 group 5.54 ms, 2 groups 5.70 ms, 4 groups
+    // 7.36 ms alone, and 10.5 / 10.8 / 11.2 ms per overlapped step -- twice the launches cost more host and queue time than the
+    // concurrency returns, so the default stays ONE group; GORIO_UGPM_GROUPS overrides it for experiments.  The arithmetic of a
+    // window does not depend on the grouping.
+    int n_groups = 1;
+    if (const char* e = std::getenv("GORIO_UGPM_GROUPS")) n_groups = std::atoi(e);
+    n_groups = std::max(1, std::min(std::min(n_groups, 8), nw));
+    while ((int)c.groups.size() < n_groups) {
+      Ctx::Group gnew;
+      if (c.groups.empty()) {
+        gnew.s = c.stream;
+        gnew.s2 = c.stream2;
+        gnew.ev_jac = c.ev_jac;
+        gnew.ev_corr = c.ev_corr;
+      } else {
+        int lo = 0, hi = 0;
+        if (!(hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(&gnew.s, hipStreamNonBlocking, hi) == hipSuccess))
+          UHIP(hipStreamCreateWithFlags(&gnew.s, hipStreamNonBlocking));
+        UHIP(hipStreamCreateWithFlags(&gnew.s2, hipStreamNonBlocking));
+        UHIP(hipEventCreateWithFlags(&gnew.ev_jac, hipEventDisableTiming));
+        UHIP(hipEventCreateWithFlags(&gnew.ev_corr, hipEventDisableTiming));
+      }
+      UHIP(hipEventCreateWithFlags(&gnew.ev_done, hipEventDisableTiming));
+      c.groups.push_back(gnew);
+    }
+    if (!c.ev_up) UHIP(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
+    UHIP(hipEventRecord(c.ev_up, c.stream));  // inputs, window descriptors and control words are on the device once this fires
+    struct Run { int g0, nw; hipStream_t s, s2; hipEvent_t ev_jac, ev_corr, ev_done; bool active; };
+    std::vector<Run> runs(n_groups);
+    for (int g = 0; g < n_groups; ++g) {
+      const int a = (int)((long)nw * g / n_groups), b = (int)((long)nw * (g + 1) / n_groups);
+      runs[g] = Run{a, b - a, c.groups[g].s, c.groups[g].s2, c.groups[g].ev_jac, c.groups[g].ev_corr, c.groups[g].ev_done, true};
+      if (g > 0) UHIP(hipStreamWaitEvent(runs[g].s, c.ev_up, 0));
+    }
     // J^T J launches: one workgroup per (row slice, tile group, window), see ata_kernel
-    auto launch_ata = [&](int which) {
-      hipStream_t sq = which == 2 ? c.stream2 : c.stream;
+    auto launch_ata = [&](const Run& r, int which) {
+      hipStream_t sq = which == 2 ? r.s2 : r.s;
       Stage st_ata(c, which == 2 ? 6 : 5, sq);
       const int n = (which == 2 ? 6 : 3) * max_S, T = (n + 15) / 16, ntile = T * (T + 1) / 2;
       const int tpg = which == 2 ? kAtaTilesCorr : kAtaTilesLm;
       const int ng = (ntile + tpg - 1) / tpg;
       const int npad = ((n + 15) / 32) * 32 + 16;
-      const int units = nw * ng, grid = ((units + 7) / 8) * kAtaKSplit * 8;
+      const int units = r.nw * ng, grid = ((units + 7) / 8) * kAtaKSplit * 8;
+      const UgpmWin* dw_ = c.d_wins + r.g0;
       // LDS as small as the staging needs (53 KB at n = 198): the scan matcher's kernels share the CUs with these workgroups
       auto lds = [&](int kc) { return sizeof(double) * 2 * kc * (npad + 1); };
       if (which == 2) {
-        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(c.d_wins, which, nw, ng);
-        else if (npad <= 512) ug::ata_kernel<8, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(c.d_wins, which, nw, ng);
-        else ug::ata_kernel<16, 8, kAtaTilesCorr><<<grid, 512, lds(8), sq>>>(c.d_wins, which, nw, ng);
+        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng);
+        else if (npad <= 512) ug::ata_kernel<8, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng);
+        else ug::ata_kernel<16, 8, kAtaTilesCorr><<<grid, 512, lds(8), sq>>>(dw_, which, r.nw, ng);
       } else {
-        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(c.d_wins, which, nw, ng);
-        else ug::ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(c.d_wins, which, nw, ng);  // n = 3S <= 480
+        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng);
+        else ug::ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng);  // n = 3S <= 480
       }
     };
-    {
-      Stage st(c, 0);
-      ug::lpm_rot_kernel<<<dim3(nw, 5), 320, 0, c.stream>>>(c.d_wins);
-      ug::lpm_init_kernel<<<nw, 320, 0, c.stream>>>(c.d_wins);
+    for (const Run& r : runs) {
+      const UgpmWin* dw_ = c.d_wins + r.g0;
+      {
+        Stage st(c, 0, r.s);
+        ug::lpm_rot_kernel<<<dim3(r.nw, 5), 320, 0, r.s>>>(dw_);
+        ug::lpm_init_kernel<<<r.nw, 320, 0, r.s>>>(dw_);
+      }
+      {
+        Stage st(c, 1, r.s);
+        ug::gram_kernel<<<dim3(6, r.nw), 256, 0, r.s>>>(dw_);
+        ug::cross_kernel<<<dim3(12, r.nw, (std::max(max_G, max_V) + ug::kCrossRows - 1) / ug::kCrossRows), 256, 0, r.s>>>(dw_);
+      }
+      // State correlation at the LPM-initialised state.  The reference assembles the Jacobian synchronously (preint.h:887-937) and
+      // hands J^T J, its factorisation and the inverse diagonal to a helper thread that runs beside the two ceres::Solve calls and is
+      // joined before the first get() (preint.h:939, 1062-1065); here the Jacobian is written on the main stream (the fits then change
+      // the states it is evaluated at) and the rest of the chain runs on a second stream that the inference waits for.
+      ug::corr_jac_kernel<<<dim3(ug::kCorrJacParts, r.nw), 256, 0, r.s>>>(dw_);
+      UHIP(hipEventRecord(r.ev_jac, r.s));
+      UHIP(hipStreamWaitEvent(r.s2, r.ev_jac, 0));
+      {
+        Stage st(c, 2, r.s2);
+        launch_ata(r, 2);
+        ug::corr_factor_kernel<<<r.nw, 512, 0, r.s2>>>(dw_);
+        ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, r.nw), 256, sizeof(double) * 17 * (6 * max_S + 16), r.s2>>>(dw_);
+      }
+      UHIP(hipEventRecord(r.ev_corr, r.s2));
     }
-    {
-      Stage st(c, 1);
-      ug::gram_kernel<<<dim3(6, nw), 256, 0, c.stream>>>(c.d_wins);
-      ug::cross_kernel<<<dim3(12, nw, (std::max(max_G, max_V) + ug::kCrossRows - 1) / ug::kCrossRows), 256, 0, c.stream>>>(c.d_wins);
-    }
-    // State correlation at the LPM-initialised state.  The reference assembles the Jacobian synchronously (preint.h:887-937) and
-    // hands J^T J, its factorisation and the inverse diagonal to a helper thread that runs beside the two ceres::Solve calls and is
-    // joined before the first get() (preint.h:939, 1062-1065); here the Jacobian is written on the main stream (the fits then change
-    // the states it is evaluated at) and the rest of the chain runs on a second stream that the inference waits for.
-    ug::corr_jac_kernel<<<dim3(ug::kCorrJacParts, nw), 256, 0, c.stream>>>(c.d_wins);
-    UHIP(hipEventRecord(c.ev_jac, c.stream));
-    UHIP(hipStreamWaitEvent(c.stream2, c.ev_jac, 0));
-    {
-      Stage st(c, 2, c.stream2);
-      launch_ata(2);
-      ug::corr_factor_kernel<<<nw, 512, 0, c.stream2>>>(c.d_wins);
-      ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, nw), 256, sizeof(double) * 17 * (6 * max_S + 16), c.stream2>>>(c.d_wins);
-    }
-    UHIP(hipEventRecord(c.ev_corr, c.stream2));
     std::vector<int> flags(kWinInts * (size_t)nw);
     for (int problem = 0; problem < 2; ++problem) {  // ceres::Solve #1 (rotation) and #2 (velocity), preint.h:943-967
-      Stage st(c, 3);
-      ug::lm_begin_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, problem);
-      if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 2);
-      else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 2);
-      launch_ata(problem);
+      std::vector<std::unique_ptr<Stage>> st_lm;
+      for (Run& r : runs) {
+        const UgpmWin* dw_ = c.d_wins + r.g0;
+        st_lm.emplace_back(new Stage(c, 3, r.s));
+        ug::lm_begin_kernel<<<r.nw, 256, 0, r.s>>>(dw_, problem);
+        if (problem == 0) ug::rot_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 2);
+        else ug::vel_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 2);
+        launch_ata(r, problem);
+        r.active = true;
+      }
       for (int it = 0; it <= 51; ++it) {
-        ug::lm_step_kernel<<<nw, 512, 0, c.stream>>>(c.d_wins);
-        if (problem == 0) ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
-        else ug::vel_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 0);
-        if (problem == 0) {
-          ug::rot_eval_kernel<<<dim3(nw, kEvalSplit), 256, 0, c.stream>>>(c.d_wins, 1);
-          launch_ata(problem);
-        } else {
-          ug::lm_relinearize_linear_kernel<<<dim3(nw, (3 * max_S + 63) / 64), 256, 0, c.stream>>>(c.d_wins);  // linear problem: J and J^T J stay exact
+        bool any = false;
+        for (Run& r : runs) {
+          if (!r.active) continue;
+          any = true;
+          const UgpmWin* dw_ = c.d_wins + r.g0;
+          ug::lm_step_kernel<<<r.nw, 512, 0, r.s>>>(dw_);
+          if (problem == 0) ug::rot_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 0);
+          else ug::vel_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 0);
+          if (problem == 0) {
+            ug::rot_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 1);
+            launch_ata(r, problem);
+          } else {
+            ug::lm_relinearize_linear_kernel<<<dim3(r.nw, (3 * max_S + 63) / 64), 256, 0, r.s>>>(dw_);  // linear problem: J and J^T J stay exact
+          }
         }
+        if (!any) break;
         if (it >= 3 && (it & 1) == 1) {  // poll the done flags every other iteration (no window of the C2 shape finishes in fewer than four)
-          UHIP(hipMemcpyAsync(flags.data(), c.d_ints, sizeof(int) * flags.size(), hipMemcpyDeviceToHost, c.stream));
-          UHIP(hipStreamSynchronize(c.stream));
-          bool all = true;
-          for (int i = 0; i < nw; ++i) all = all && (flags[kWinInts * (size_t)i + 1] || flags[kWinInts * (size_t)i + 16] != 0);
-          if (all) break;
+          for (Run& r : runs)
+            if (r.active) UHIP(hipMemcpyAsync(flags.data() + kWinInts * (size_t)r.g0, c.d_ints + kWinInts * (size_t)r.g0, sizeof(int) * kWinInts * (size_t)r.nw, hipMemcpyDeviceToHost, r.s));
+          for (Run& r : runs) {
+            if (!r.active) continue;
+            UHIP(hipStreamSynchronize(r.s));
+            bool all = true;
+            for (int i = r.g0; i < r.g0 + r.nw; ++i) all = all && (flags[kWinInts * (size_t)i + 1] || flags[kWinInts * (size_t)i + 16] != 0);
+            if (all) r.active = false;
+          }
         }
       }
-      ug::lm_end_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins, problem, c.d_diag);
+      for (size_t g = 0; g < runs.size(); ++g) {
+        ug::lm_end_kernel<<<runs[g].nw, 256, 0, runs[g].s>>>(c.d_wins + runs[g].g0, problem, c.d_diag + 4 * (size_t)runs[g].g0);
+        st_lm[g].reset();  // stage stop event behind the group's last launch of this problem
+      }
     }
-    UHIP(hipStreamWaitEvent(c.stream, c.ev_corr, 0));  // join of the correlation chain (preint.h:1062-1065)
-    {
-      Stage st(c, 4);
-      ug::finish_kernel<<<nw, 256, 0, c.stream>>>(c.d_wins);
-      ug::infer_kernel<<<dim3(std::max(1, max_infer), nw), 256, sizeof(double) * 17 * (6 * max_S + 16), c.stream>>>(c.d_wins);
+    for (Run& r : runs) {
+      const UgpmWin* dw_ = c.d_wins + r.g0;
+      UHIP(hipStreamWaitEvent(r.s, r.ev_corr, 0));  // join of the correlation chain (preint.h:1062-1065)
+      {
+        Stage st(c, 4, r.s);
+        ug::finish_kernel<<<r.nw, 256, 0, r.s>>>(dw_);
+        ug::infer_kernel<<<dim3(std::max(1, max_infer), r.nw), 256, sizeof(double) * 17 * (6 * max_S + 16), r.s>>>(dw_);
+      }
+      UHIP(hipEventRecord(r.ev_done, r.s));
     }
+    for (size_t g = 1; g < runs.size(); ++g) UHIP(hipStreamWaitEvent(c.stream, runs[g].ev_done, 0));  // the downloads below follow every group
     UHIP(hipGetLastError());
   }
   tt3 = tnow();
