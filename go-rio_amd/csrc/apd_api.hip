@@ -23,6 +23,8 @@
 #include "apd_kernels.hip"
 #include "apd_index.hip"
 #include "apd_submap.hip"
+#include "apd_prep.hip"
+#include "../../include/gorio_prep.h"
 
 using namespace gorio;
 
@@ -1488,6 +1490,180 @@ int gorio_apd_get_stage_times(gorio_apd_t* h, double seconds[8], int counts[8]) 
     if (seconds) seconds[i] = h->stage_s[i];
     if (counts) counts[i] = h->stage_n[i];
   }
+  return GORIO_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================== preprocessing (include/gorio_prep.h)
+
+namespace {
+thread_local std::string g_prep_err;
+int prep_fail(int code, const std::string& m) {
+  g_prep_err = m;
+  return code;
+}
+struct PrepCtx {  // per thread: a private registration handle serves as the device-side cloud + search-index holder
+  gorio_apd* h = nullptr;
+  int device = -1;
+  int* d_cnt = nullptr;
+  long long* d_offs = nullptr;
+  int* d_adj = nullptr;
+  size_t pts_cap = 0, adj_cap = 0;
+  ~PrepCtx() {
+    if (h) {
+      hipSetDevice(device);
+      hipFree(d_cnt); hipFree(d_offs); hipFree(d_adj);
+      gorio_apd_destroy(h);
+    }
+  }
+};
+thread_local PrepCtx g_prep;
+}  // namespace
+
+extern "C" {
+
+const char* gorio_prep_last_error(void) { return g_prep_err.c_str(); }
+
+int gorio_prep_dbscan_labels(int device, const float* xyz, int n, int point_stride_bytes, double eps, int core_min_pts, int min_cluster_size, int max_cluster_size,
+                             float* label_out, int label_stride_bytes, int* n_clusters) {
+  if (!xyz || !label_out || n <= 0 || point_stride_bytes < 12 || (point_stride_bytes % 4) || label_stride_bytes < 4 || (label_stride_bytes % 4))
+    return prep_fail(GORIO_ERR_INVALID, "dbscan_labels: bad arguments");
+  PrepCtx& c = g_prep;
+  if (!c.h || c.device != device) {
+    if (c.h) {
+      hipSetDevice(c.device);
+      hipFree(c.d_cnt); hipFree(c.d_offs); hipFree(c.d_adj);
+      gorio_apd_destroy(c.h);
+      c = PrepCtx();
+    }
+    const int rc = gorio_apd_create(&c.h, device);
+    if (rc) return prep_fail(rc, "dbscan_labels: no usable HIP device (there is no CPU fallback)");
+    c.device = device;
+  }
+  gorio_apd* h = c.h;
+  h->params.search = GORIO_SEARCH_PRUNED;
+  int rc = gorio_apd_set_source(h, xyz, nullptr, n, point_stride_bytes);
+  if (rc) return prep_fail(rc, h->err);
+#define PREP_HIP(expr)                                                                                   \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return prep_fail(GORIO_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+  {
+    std::vector<std::pair<gorio_apd*, DevCloud*>> one = {{h, h->src.get()}};
+    rc = run_index_build(h, one);
+    if (rc) return prep_fail(rc, h->err);
+  }
+  if ((size_t)n > c.pts_cap) {
+    hipFree(c.d_cnt); hipFree(c.d_offs);
+    c.d_cnt = nullptr; c.d_offs = nullptr;
+    c.pts_cap = 0;
+    PREP_HIP(hipMalloc(&c.d_cnt, sizeof(int) * ((size_t)n + n / 8)));
+    PREP_HIP(hipMalloc(&c.d_offs, sizeof(long long) * ((size_t)n + n / 8)));
+    c.pts_cap = (size_t)n + n / 8;
+  }
+  const CloudView cv = h->src->view();
+  const int grid = (roundup(n, 512) + 255) / 256;
+  RadiusArgs ra{eps, c.d_cnt, c.d_offs, nullptr};
+  radius_neighbours_kernel<0><<<grid, 256, 0, h->stream>>>(cv, ra);
+  PREP_HIP(hipGetLastError());
+  std::vector<int> cnt((size_t)n);
+  PREP_HIP(hipMemcpyAsync(cnt.data(), c.d_cnt, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  PREP_HIP(hipStreamSynchronize(h->stream));
+  std::vector<long long> offs((size_t)n + 1);
+  offs[0] = 0;
+  for (int i = 0; i < n; ++i) offs[i + 1] = offs[i] + cnt[i];
+  const long long E = offs[n];
+  if ((size_t)E > c.adj_cap) {
+    hipFree(c.d_adj);
+    c.d_adj = nullptr;
+    c.adj_cap = 0;
+    PREP_HIP(hipMalloc(&c.d_adj, sizeof(int) * ((size_t)E + (size_t)E / 8 + 16)));
+    c.adj_cap = (size_t)E + (size_t)E / 8 + 16;
+  }
+  PREP_HIP(hipMemcpyAsync(c.d_offs, offs.data(), sizeof(long long) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  ra.adj = c.d_adj;
+  radius_neighbours_kernel<1><<<grid, 256, 0, h->stream>>>(cv, ra);
+  PREP_HIP(hipGetLastError());
+  std::vector<int> adj((size_t)E);
+  if (E > 0) PREP_HIP(hipMemcpyAsync(adj.data(), c.d_adj, sizeof(int) * (size_t)E, hipMemcpyDeviceToHost, h->stream));
+  PREP_HIP(hipStreamSynchronize(h->stream));
+#undef PREP_HIP
+
+  // ---- the queue of DBSCAN_simple.h:28-100, statement for statement, over the adjacency (the radius searches are done)
+  enum : unsigned char { UN = 0, PROCESSING = 1, PROCESSED = 2 };
+  std::vector<unsigned char> types((size_t)n, UN), noise((size_t)n, 0);
+  std::vector<int> queue;
+  std::vector<std::vector<int>> clusters;
+  auto seed_count = [&](int i) { return cnt[i]; };  // |N(i, seed radius)|, the point itself included
+  auto exp_count = [&](int i) {
+    int k = 0;
+    for (long long e = offs[i]; e < offs[i + 1]; ++e) k += (adj[(size_t)e] < 0);
+    return k;
+  };
+  for (int i = 0; i < n; ++i) {
+    if (types[i] == PROCESSED) continue;
+    if (seed_count(i) < core_min_pts) {
+      noise[i] = 1;
+      continue;
+    }
+    queue.clear();
+    queue.push_back(i);
+    types[i] = PROCESSED;
+    for (long long e = offs[i]; e < offs[i + 1]; ++e) {
+      const int j = adj[(size_t)e] & 0x7fffffff;
+      if (j != i) {
+        queue.push_back(j);  // DBS:50-54: whatever its state
+        types[j] = PROCESSING;
+      }
+    }
+    size_t sq = 1;
+    while (sq < queue.size()) {
+      const int q = queue[sq];
+      if (noise[q] || types[q] == PROCESSED) {
+        types[q] = PROCESSED;
+        sq++;
+        continue;
+      }
+      if (exp_count(q) >= core_min_pts) {
+        for (long long e = offs[q]; e < offs[q + 1]; ++e) {
+          if (adj[(size_t)e] >= 0) continue;  // outside the expansion radius
+          const int j = adj[(size_t)e] & 0x7fffffff;
+          if (types[j] == UN) {
+            queue.push_back(j);
+            types[j] = PROCESSING;
+          }
+        }
+      }
+      types[q] = PROCESSED;
+      sq++;
+    }
+    if ((int)queue.size() >= min_cluster_size && (int)queue.size() <= max_cluster_size) clusters.push_back(queue);  // DBS:83-95
+  }
+  // ---- preprocessing_nodelet_ntu.cpp:533-568: rank the clusters by the distance of their centroid, write rank + 1
+  const int st = point_stride_bytes / 4, lst = label_stride_bytes / 4;
+  for (int i = 0; i < n; ++i) label_out[(size_t)i * lst] = 0.0f;
+  const int nc = (int)clusters.size();
+  std::vector<float> dist((size_t)nc);
+  std::vector<int> order((size_t)nc);
+  for (int cidx = 0; cidx < nc; ++cidx) {
+    std::vector<int>& m = clusters[cidx];
+    std::sort(m.begin(), m.end());  // DBS:91
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int idx : m) {
+      const float* p = xyz + (size_t)idx * st;
+      sx += p[0]; sy += p[1]; sz += p[2];
+    }
+    const int num = (int)m.size();
+    const float cx = sx / num, cy = sy / num, cz = sz / num;
+    dist[cidx] = (float)std::sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);  // std::hypot(float, float, float)
+    order[cidx] = cidx;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dist[a] < dist[b]; });
+  for (int r = 0; r < nc; ++r)
+    for (int idx : clusters[order[r]]) label_out[(size_t)idx * lst] = (float)(r + 1);
+  if (n_clusters) *n_clusters = nc;
   return GORIO_OK;
 }
 

@@ -215,3 +215,12 @@ def submap_assemble(frames, rel_poses, voxel_leaf=0.0):
     if n < 0:
         raise RuntimeError("apdo_submap_assemble failed")
     return ox[:n].copy(), ol[:n].copy()
+
+
+def dbscan_labels(xyz, eps=0.9, min_pts=10, min_cluster=20, max_cluster=25000):
+    """preprocessing_nodelet_ntu.cpp:518-568: DBSCAN cluster labels (normal_x) of one scan, ranked by centroid distance; 0 = unclustered."""
+    xyz = _f32(xyz)
+    n = xyz.shape[0]
+    lab = np.zeros(max(n, 1), np.float32)
+    nc = lib().apdo_dbscan_labels(_p(xyz, C.c_float), n, C.c_double(eps), int(min_pts), int(min_cluster), int(max_cluster), _p(lab, C.c_float))
+    return lab[:n].copy(), int(nc)

@@ -1111,3 +1111,139 @@ int apdo_submap_assemble(const float* xyz /* all frames, packed n x 3 */, const 
   free(tl);
   return n_out;
 }
+
+/* ------------------------------------------------------------------------------------------------ preprocessing: DBSCAN cluster labels
+ *
+ * PREP = /root/reference/4DRadarSLAM/apps/preprocessing_nodelet_ntu.cpp, DBS = /root/reference/4DRadarSLAM/include/dbscan/DBSCAN_simple.h.
+ * PREP:518-568: DBSCANKdtreeCluster (core min points 10, tolerance 0.9, cluster size 20..25000) over the whole scan; clusters ranked by
+ * the distance of their centroid from the sensor; normal_x = rank + 1 for their points, 0 elsewhere -- the cluster label APD:272 compares.
+ * DBS:28-100 is an order-dependent queue: points are visited in index order; an unprocessed point whose neighbourhood (radius
+ * |norm - 1| / 50 + eps, DBS:39) holds at least minPts points (itself included) seeds a cluster; queue members are expanded with the
+ * radius (norm - 1) / 100 + eps (DBS:65-68) and claim every still unprocessed neighbour; a point already claimed is never re-claimed.
+ * Third-party behaviour restated ("parity unpinned": PCL / FLANN are not under /root/reference): pcl::search::KdTree::radiusSearch
+ * (index, radius) = exact FLANN radius search on float L2_Simple squared distances, a neighbour when d2 < (float)(radius * radius)
+ * (flann RadiusResultSet::addPoint), the query point itself included.  The order of the neighbours does not influence the result.
+ * std::hypot(float x3) is restated as the correctly rounded float of the double norm; ties between centroid distances keep discovery order.
+ * labels_out[n]; returns the number of clusters.
+ */
+int apdo_dbscan_labels(const float* xyz, int n, double eps, int min_pts, int min_cluster, int max_cluster, float* labels_out) {
+  enum { UN = 0, PROCESSING = 1, PROCESSED = 2 };
+  const size_t nn_ = (size_t)(n > 0 ? n : 1);
+  unsigned char* types = (unsigned char*)calloc(nn_, 1);
+  unsigned char* noise = (unsigned char*)calloc(nn_, 1);
+  int* queue = (int*)malloc(sizeof(int) * nn_);
+  int* nn = (int*)malloc(sizeof(int) * nn_);
+  /* accepted clusters: member lists packed one after the other (a point can be in several: DBS:50-54 re-queue seed neighbours that an
+   * earlier cluster already holds) */
+  size_t mem_cap = nn_ * 2, mem_n = 0;
+  int* members = (int*)malloc(sizeof(int) * mem_cap);
+  int clu_cap = 64, n_clusters = 0;
+  size_t* clu_begin = (size_t*)malloc(sizeof(size_t) * (size_t)(clu_cap + 1));
+  clu_begin[0] = 0;
+  for (int i = 0; i < n; i++) labels_out[i] = 0.0f;
+#define APDO_NORM(q) ((double)sqrtf(xyz[3 * (size_t)(q)] * xyz[3 * (size_t)(q)] + xyz[3 * (size_t)(q) + 1] * xyz[3 * (size_t)(q) + 1] + xyz[3 * (size_t)(q) + 2] * xyz[3 * (size_t)(q) + 2]))
+#define APDO_RADIUS_SEARCH(q, radius, count)                                            \
+  do {                                                                                   \
+    const float r2_ = (float)((radius) * (radius));                                      \
+    const float qx_ = xyz[3 * (size_t)(q)], qy_ = xyz[3 * (size_t)(q) + 1], qz_ = xyz[3 * (size_t)(q) + 2]; \
+    (count) = 0;                                                                         \
+    for (int j_ = 0; j_ < n; j_++) {                                                     \
+      const float dx_ = qx_ - xyz[3 * (size_t)j_], dy_ = qy_ - xyz[3 * (size_t)j_ + 1], dz_ = qz_ - xyz[3 * (size_t)j_ + 2]; \
+      float d_ = dx_ * dx_;                                                              \
+      d_ = d_ + dy_ * dy_;                                                               \
+      d_ = d_ + dz_ * dz_;                                                               \
+      if (d_ < r2_) nn[(count)++] = j_;                                                  \
+    }                                                                                    \
+  } while (0)
+  for (int i = 0; i < n; i++) {
+    if (types[i] == PROCESSED) continue;
+    const double r_seed = fabs(APDO_NORM(i) - 1) / 50 + eps; /* DBS:36-39: float products summed in float, std::sqrt(float) -> float, then double arithmetic */
+    int cnt = 0;
+    APDO_RADIUS_SEARCH(i, r_seed, cnt);
+    if (cnt < min_pts) {
+      noise[i] = 1;
+      continue;
+    }
+    int qn = 0;
+    queue[qn++] = i;
+    types[i] = PROCESSED;
+    for (int j = 0; j < cnt; j++)
+      if (nn[j] != i) {
+        queue[qn++] = nn[j]; /* DBS:50-54: every neighbour of the seed joins the queue, whatever its state */
+        types[nn[j]] = PROCESSING;
+      }
+    int sq = 1;
+    while (sq < qn) {
+      const int c = queue[sq];
+      if (noise[c] || types[c] == PROCESSED) {
+        types[c] = PROCESSED;
+        sq++;
+        continue;
+      }
+      const double r_exp = (APDO_NORM(c) - 1) / 100 + eps; /* DBS:65-67 */
+      APDO_RADIUS_SEARCH(c, r_exp, cnt);
+      if (cnt >= min_pts)
+        for (int j = 0; j < cnt; j++)
+          if (types[nn[j]] == UN) {
+            queue[qn++] = nn[j];
+            types[nn[j]] = PROCESSING;
+          }
+      types[c] = PROCESSED;
+      sq++;
+    }
+    if (qn >= min_cluster && qn <= max_cluster) { /* DBS:83-95 (the queue holds no duplicate, so sort + unique only orders it) */
+      if (mem_n + (size_t)qn > mem_cap) {
+        mem_cap = (mem_n + (size_t)qn) * 2;
+        members = (int*)realloc(members, sizeof(int) * mem_cap);
+      }
+      if (n_clusters + 1 > clu_cap) {
+        clu_cap *= 2;
+        clu_begin = (size_t*)realloc(clu_begin, sizeof(size_t) * (size_t)(clu_cap + 1));
+      }
+      memcpy(members + mem_n, queue, sizeof(int) * (size_t)qn);
+      mem_n += (size_t)qn;
+      clu_begin[++n_clusters] = mem_n;
+    }
+  }
+#undef APDO_RADIUS_SEARCH
+#undef APDO_NORM
+  /* PREP:533-568: centroid (float sums over the SORTED member list, DBS:91), distance from the sensor, labels written cluster by cluster in
+   * ascending distance, so a point two clusters share ends with the label of the farther one */
+  if (n_clusters > 0) {
+    float* dist = (float*)malloc(sizeof(float) * (size_t)n_clusters);
+    int* order = (int*)malloc(sizeof(int) * (size_t)n_clusters);
+    unsigned char* in = (unsigned char*)calloc(nn_, 1);
+    for (int c = 0; c < n_clusters; c++) {
+      const int* m = members + clu_begin[c];
+      const int cnt = (int)(clu_begin[c + 1] - clu_begin[c]);
+      for (int j = 0; j < cnt; j++) in[m[j]] = 1;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      for (int i = 0; i < n; i++) /* ascending index = the sorted indices vector */
+        if (in[i]) {
+          sx += xyz[3 * (size_t)i];
+          sy += xyz[3 * (size_t)i + 1];
+          sz += xyz[3 * (size_t)i + 2];
+          in[i] = 0;
+        }
+      const float cx = sx / cnt, cy = sy / cnt, cz = sz / cnt;
+      dist[c] = (float)sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);
+      order[c] = c;
+    }
+    for (int a = 1; a < n_clusters; a++) { /* stable insertion sort by distance */
+      const int v = order[a];
+      int b = a - 1;
+      while (b >= 0 && dist[order[b]] > dist[v]) {
+        order[b + 1] = order[b];
+        b--;
+      }
+      order[b + 1] = v;
+    }
+    for (int r = 0; r < n_clusters; r++) {
+      const int c = order[r];
+      for (size_t j = clu_begin[c]; j < clu_begin[c + 1]; j++) labels_out[members[j]] = (float)(r + 1);
+    }
+    free(in); free(order); free(dist);
+  }
+  free(clu_begin); free(members); free(nn); free(queue); free(noise); free(types);
+  return n_clusters;
+}

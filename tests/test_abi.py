@@ -31,6 +31,8 @@ def test_binding_covers_header(gorio):
     assert sorted(apd.APD_SYMBOLS) == _declared("gorio_apd.h")
     ugpm = import_module("go-rio_amd.ugpm")
     assert sorted(ugpm.UGPM_SYMBOLS) == _declared("gorio_ugpm.h")
+    prep = import_module("go-rio_amd.prep")
+    assert sorted(prep.PREP_SYMBOLS) == _declared("gorio_prep.h")
 
 
 def test_default_params_match_reference_defaults(gorio):
