@@ -1669,6 +1669,263 @@ int gorio_prep_dbscan_labels(int device, const float* xyz, int n, int point_stri
 
 }  // extern "C"
 
+// ----------------------------------------------------------------------------------------------- REVE (include/gorio_prep.h)
+namespace {
+
+void host_ldlt3_solve(const double* A_in, const double* rhs, double* x) {  // Eigen::LDLT<3x3>: the 6 x 6 routine of the kernels, n = 3
+  double A[9];
+  int perm[3] = {0, 1, 2};
+  std::memcpy(A, A_in, sizeof(A));
+  for (int k = 0; k < 3; ++k) {
+    int piv = k;
+    double best = std::fabs(A[k * 3 + k]);
+    for (int i = k + 1; i < 3; ++i)
+      if (std::fabs(A[i * 3 + i]) > best) {
+        best = std::fabs(A[i * 3 + i]);
+        piv = i;
+      }
+    if (piv != k) {
+      for (int c = 0; c < 3; ++c) std::swap(A[k * 3 + c], A[piv * 3 + c]);
+      for (int r = 0; r < 3; ++r) std::swap(A[r * 3 + k], A[r * 3 + piv]);
+      std::swap(perm[k], perm[piv]);
+    }
+    const double d = A[k * 3 + k];
+    if (d == 0.0) continue;
+    double col[3];
+    for (int i = k + 1; i < 3; ++i) col[i] = A[i * 3 + k];
+    for (int i = k + 1; i < 3; ++i) {
+      const double l = col[i] / d;
+      for (int j = k + 1; j <= i; ++j) A[i * 3 + j] -= l * col[j];
+      A[i * 3 + k] = l;
+    }
+    for (int i = k + 1; i < 3; ++i)
+      for (int j = i + 1; j < 3; ++j) A[i * 3 + j] = A[j * 3 + i];
+  }
+  double y[3];
+  for (int i = 0; i < 3; ++i) y[i] = rhs[perm[i]];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < i; ++j) y[i] -= A[i * 3 + j] * y[j];
+  for (int i = 0; i < 3; ++i) y[i] = (A[i * 3 + i] != 0.0) ? y[i] / A[i * 3 + i] : 0.0;
+  for (int i = 2; i >= 0; --i)
+    for (int j = i + 1; j < 3; ++j) y[i] -= A[j * 3 + i] * y[j];
+  for (int i = 0; i < 3; ++i) x[perm[i]] = y[i];
+}
+
+struct ReveCtx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  float* d_in = nullptr;
+  double* d_f = nullptr;
+  double* d_fv = nullptr;
+  unsigned char* d_valid = nullptr;
+  unsigned char* d_flags = nullptr;
+  double* d_v = nullptr;
+  double* d_out = nullptr;
+  size_t cap = 0, flags_cap = 0;
+};
+thread_local ReveCtx g_reve;
+
+}  // namespace
+
+extern "C" {
+
+void gorio_prep_reve_default_config(gorio_reve_config* c) {  // radar_ego_velocity_estimator.h:30-60
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->min_dist = 1; c->max_dist = 400; c->min_db = 0; c->elevation_thresh_deg = 22.5f; c->azimuth_thresh_deg = 56.5f; c->doppler_velocity_correction_factor = 1;
+  c->thresh_zero_velocity = 0.05f; c->allowed_outlier_percentage = 0.30f; c->sigma_zero_velocity_x = 1.0e-03f; c->sigma_zero_velocity_y = 3.2e-03f; c->sigma_zero_velocity_z = 1.0e-02f;
+  c->max_sigma_x = 0.2f; c->max_sigma_y = 0.2f; c->max_sigma_z = 0.2f; c->inlier_thresh = 0.5f; c->use_ransac = 1; c->n_ransac_points = 5;
+  c->outlier_prob = 0.05f; c->success_prob = 0.995f;
+}
+
+int gorio_prep_reve_ransac_iterations(const gorio_reve_config* c) {  // setRansacIter, radar_ego_velocity_estimator.h:138-141
+  if (!c) return 0;
+  return (int)(unsigned int)((std::log(1.0 - c->success_prob)) / std::log(1.0 - std::pow(1.0 - c->outlier_prob, (float)c->n_ransac_points)));
+}
+
+int gorio_prep_ego_velocity(int device, const float* xyz, const float* intensity, const float* doppler, int n, int stride_bytes, const gorio_reve_config* cfg,
+                            const unsigned int* sample_idx, int n_iter, double v_r[3], double sigma_v_r[3], unsigned char* inlier_mask, unsigned char* outlier_mask,
+                            int* n_valid, int* zero_velocity, int* success) {
+  if (!xyz || !intensity || !doppler || !cfg || !v_r || !sigma_v_r || n <= 0 || stride_bytes < 4 || (stride_bytes % 4) || n_iter < 0 || (n_iter > 0 && !sample_idx) || cfg->n_ransac_points < 3 || cfg->n_ransac_points > 64)
+    return prep_fail(GORIO_ERR_INVALID, "ego_velocity: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return prep_fail(GORIO_ERR_NO_DEVICE, "ego_velocity: no usable HIP device (there is no CPU fallback)");
+  if (device < 0 || device >= ndev) return prep_fail(GORIO_ERR_INVALID, "ego_velocity: bad device ordinal");
+#define REVE_HIP(expr)                                                                                   \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return prep_fail(GORIO_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+  REVE_HIP(hipSetDevice(device));
+  ReveCtx& c = g_reve;
+  if (c.device != device) {
+    c = ReveCtx();
+    c.device = device;
+    c.stream = device_stream(device);
+    if (!c.stream) return prep_fail(GORIO_ERR_NO_DEVICE, "ego_velocity: no stream");
+    REVE_HIP(hipMalloc(&c.d_v, sizeof(double) * 3 * 64));
+  }
+  if ((size_t)n > c.cap) {
+    hipFree(c.d_in); hipFree(c.d_f); hipFree(c.d_fv); hipFree(c.d_valid); hipFree(c.d_out);
+    const size_t cap = (size_t)n + n / 8;
+    REVE_HIP(hipMalloc(&c.d_in, sizeof(float) * 5 * cap));
+    REVE_HIP(hipMalloc(&c.d_f, sizeof(double) * 4 * cap));
+    REVE_HIP(hipMalloc(&c.d_fv, sizeof(double) * 4 * cap));
+    REVE_HIP(hipMalloc(&c.d_valid, cap));
+    REVE_HIP(hipMalloc(&c.d_out, sizeof(double) * 10 * (cap / 256 + 2)));
+    c.cap = cap;
+  }
+  // ---- per-target features on the device
+  const int st = stride_bytes / 4;
+  std::vector<float> in((size_t)n * 5);
+  for (int i = 0; i < n; ++i) {
+    in[5 * (size_t)i] = xyz[(size_t)i * st]; in[5 * (size_t)i + 1] = xyz[(size_t)i * st + 1]; in[5 * (size_t)i + 2] = xyz[(size_t)i * st + 2];
+    in[5 * (size_t)i + 3] = intensity[(size_t)i * st]; in[5 * (size_t)i + 4] = doppler[(size_t)i * st];
+  }
+  REVE_HIP(hipMemcpyAsync(c.d_in, in.data(), sizeof(float) * in.size(), hipMemcpyHostToDevice, c.stream));
+  ReveCfg rc;
+  rc.min_dist = cfg->min_dist; rc.max_dist = cfg->max_dist; rc.min_db = cfg->min_db;
+  rc.az_lim = (double)cfg->azimuth_thresh_deg * M_PI / 180.0; rc.el_lim = (double)cfg->elevation_thresh_deg * M_PI / 180.0;  // angles::from_degrees
+  rc.doppler_factor_unused = 0; rc.doppler_factor = cfg->doppler_velocity_correction_factor; rc.pad_ = 0;
+  reve_features_kernel<<<(n + 255) / 256, 256, 0, c.stream>>>(c.d_in, c.d_in + 3, c.d_in + 4, 5, n, rc, c.d_f, c.d_valid);
+  REVE_HIP(hipGetLastError());
+  std::vector<double> f((size_t)n * 4);
+  std::vector<unsigned char> valid((size_t)n);
+  REVE_HIP(hipMemcpyAsync(f.data(), c.d_f, sizeof(double) * f.size(), hipMemcpyDeviceToHost, c.stream));
+  REVE_HIP(hipMemcpyAsync(valid.data(), c.d_valid, (size_t)n, hipMemcpyDeviceToHost, c.stream));
+  REVE_HIP(hipStreamSynchronize(c.stream));
+  std::vector<int> vidx;
+  std::vector<double> fv;
+  for (int i = 0; i < n; ++i)
+    if (valid[i]) {
+      vidx.push_back(i);
+      fv.insert(fv.end(), f.begin() + 4 * (size_t)i, f.begin() + 4 * (size_t)i + 4);
+    }
+  const int m = (int)vidx.size();
+  if (inlier_mask) std::memset(inlier_mask, 0, (size_t)n);
+  if (outlier_mask) std::memset(outlier_mask, 0, (size_t)n);
+  v_r[0] = v_r[1] = v_r[2] = 0.0;
+  sigma_v_r[0] = sigma_v_r[1] = sigma_v_r[2] = 0.0;
+  if (n_valid) *n_valid = m;
+  if (zero_velocity) *zero_velocity = 0;
+  int ok = 0;
+  // solve3DFull (REVE:252-303) over the valid rows selected by `sel`: sums on the device, 3 x 3 algebra here
+  auto solve = [&](const std::vector<unsigned char>& sel, int rows, bool estimate_sigma, double* v, double* sigma) -> int {
+    const int nb = (m + 255) / 256;
+    if (hipMemcpyAsync(c.d_valid, sel.data(), (size_t)m, hipMemcpyHostToDevice, c.stream) != hipSuccess) return -1;
+    std::vector<double> part((size_t)nb * 10);
+    double s[10];
+    for (int pass = 0; pass < (estimate_sigma ? 2 : 1); ++pass) {
+      if (pass == 1 && hipMemcpyAsync(c.d_v, v, sizeof(double) * 3, hipMemcpyHostToDevice, c.stream) != hipSuccess) return -1;
+      reve_sums_kernel<<<nb, 256, 0, c.stream>>>(c.d_fv, m, c.d_valid, pass == 1 ? c.d_v : nullptr, c.d_out);
+      if (hipMemcpyAsync(part.data(), c.d_out, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c.stream) != hipSuccess || hipStreamSynchronize(c.stream) != hipSuccess) return -1;
+      for (int q = 0; q < 10; ++q) s[q] = 0.0;
+      for (int b = 0; b < nb; ++b)
+        for (int q = 0; q < 10; ++q) s[q] += part[(size_t)b * 10 + q];
+      if (pass == 0) {
+        const double HTH[9] = {s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]}, HTy[3] = {s[6], s[7], s[8]};
+        host_ldlt3_solve(HTH, HTy, v);  // use_cholesky_instead_of_bdcsvd = true: (HTH).ldlt().solve(H^T y), REVE:272
+      }
+    }
+    if (estimate_sigma) {  // REVE:278-290
+      const double H0 = s[0], H1 = s[1], H2 = s[2], H4 = s[3], H5 = s[4], H8 = s[5];
+      const double c00 = H4 * H8 - H5 * H5, c01 = H5 * H2 - H1 * H8, c02 = H1 * H5 - H4 * H2;
+      const double det = H0 * c00 + H1 * c01 + H2 * c02;
+      const double sc = s[9] / (double)(rows - 3);
+      double sg[3] = {sc * (c00 / det), sc * ((H0 * H8 - H2 * H2) / det), sc * ((H0 * H4 - H1 * H1) / det)};
+      sigma[0] = sg[0]; sigma[1] = sg[1]; sigma[2] = sg[2];
+      if (sg[0] >= 0.0 && sg[1] >= 0.0 && sg[2] >= 0.0) {
+        sigma[0] = std::sqrt(sg[0]) + cfg->sigma_offset_radar_x;
+        sigma[1] = std::sqrt(sg[1]) + cfg->sigma_offset_radar_y;
+        sigma[2] = std::sqrt(sg[2]) + cfg->sigma_offset_radar_z;
+      }
+    }
+    return 0;
+  };
+  if (m > 2) {
+    REVE_HIP(hipMemcpyAsync(c.d_fv, fv.data(), sizeof(double) * fv.size(), hipMemcpyHostToDevice, c.stream));
+    std::vector<double> vd((size_t)m);
+    for (int k = 0; k < m; ++k) vd[k] = std::fabs(fv[4 * (size_t)k + 3]);
+    const size_t nth = std::min((size_t)((double)m * (1.0 - (double)cfg->allowed_outlier_percentage)), (size_t)m - 1);
+    std::nth_element(vd.begin(), vd.begin() + nth, vd.end());  // REVE:105-108
+    if (vd[nth] < cfg->thresh_zero_velocity) {                 // REVE:110-121
+      if (zero_velocity) *zero_velocity = 1;
+      sigma_v_r[0] = cfg->sigma_zero_velocity_x; sigma_v_r[1] = cfg->sigma_zero_velocity_y; sigma_v_r[2] = cfg->sigma_zero_velocity_z;
+      if (inlier_mask)
+        for (int k = 0; k < m; ++k)
+          if (std::fabs(fv[4 * (size_t)k + 3]) < cfg->thresh_zero_velocity) inlier_mask[vidx[k]] = 1;
+      ok = 1;
+    } else if (!cfg->use_ransac) {
+      std::vector<unsigned char> all((size_t)m, 1);
+      if (solve(all, m, true, v_r, sigma_v_r)) return prep_fail(GORIO_ERR_NO_DEVICE, "ego_velocity: device error");
+      if (inlier_mask) for (int k = 0; k < m; ++k) inlier_mask[vidx[k]] = 1;
+      ok = 1;
+    } else {  // solve3DFullRansac, REVE:172-250
+      std::vector<unsigned char> best_in, best_out;
+      size_t nbi = 0, nbo = 0;
+      const int K = m >= cfg->n_ransac_points ? n_iter : 0;
+      if (K > 0) {
+        if (K > 64) return prep_fail(GORIO_ERR_INVALID, "ego_velocity: more than 64 RANSAC iterations");
+        std::vector<double> vs((size_t)K * 3);
+        for (int k = 0; k < K; ++k) {  // the sample systems are N_ransac_points rows: solved here (3 x 3)
+          double HTH[9] = {0}, HTy[3] = {0};
+          for (int q = 0; q < cfg->n_ransac_points; ++q) {
+            const unsigned int row = sample_idx[(size_t)k * cfg->n_ransac_points + q];
+            if (row >= (unsigned int)m) return prep_fail(GORIO_ERR_INVALID, "ego_velocity: sample index outside the valid targets");
+            const double* r = fv.data() + 4 * (size_t)row;
+            for (int a = 0; a < 3; ++a) {
+              for (int b = 0; b < 3; ++b) HTH[a * 3 + b] += r[a] * r[b];
+              HTy[a] += r[a] * r[3];
+            }
+          }
+          host_ldlt3_solve(HTH, HTy, vs.data() + 3 * (size_t)k);
+        }
+        if ((size_t)K * m > c.flags_cap) {
+          hipFree(c.d_flags);
+          c.d_flags = nullptr;
+          c.flags_cap = 0;
+          REVE_HIP(hipMalloc(&c.d_flags, (size_t)K * m + 1024));
+          c.flags_cap = (size_t)K * m + 1024;
+        }
+        REVE_HIP(hipMemcpyAsync(c.d_v, vs.data(), sizeof(double) * vs.size(), hipMemcpyHostToDevice, c.stream));
+        reve_eval_kernel<<<dim3((m + 255) / 256, K), 256, 0, c.stream>>>(c.d_fv, m, c.d_v, (double)cfg->inlier_thresh, c.d_flags);
+        REVE_HIP(hipGetLastError());
+        std::vector<unsigned char> flags((size_t)K * m);
+        REVE_HIP(hipMemcpyAsync(flags.data(), c.d_flags, flags.size(), hipMemcpyDeviceToHost, c.stream));
+        REVE_HIP(hipStreamSynchronize(c.stream));
+        for (int k = 0; k < K; ++k) {
+          const unsigned char* fl = flags.data() + (size_t)k * m;
+          size_t ni = 0;
+          for (int j = 0; j < m; ++j) ni += fl[j];
+          size_t no = (size_t)m - ni;
+          std::vector<unsigned char> cur_in(fl, fl + m), cur_out((size_t)m);
+          for (int j = 0; j < m; ++j) cur_out[j] = !fl[j];
+          if ((float)no / (float)(ni + no) > 0.05) {  // REVE:215-220
+            std::fill(cur_in.begin(), cur_in.end(), 1);
+            std::fill(cur_out.begin(), cur_out.end(), 0);
+            ni = (size_t)m;
+            no = 0;
+          }
+          if (ni > nbi) { best_in = cur_in; nbi = ni; }
+          if (no > nbo) { best_out = cur_out; nbo = no; }
+          v_r[0] = vs[3 * (size_t)k]; v_r[1] = vs[3 * (size_t)k + 1]; v_r[2] = vs[3 * (size_t)k + 2];
+        }
+      }
+      if (nbi > 0) {
+        if (solve(best_in, (int)nbi, true, v_r, sigma_v_r)) return prep_fail(GORIO_ERR_NO_DEVICE, "ego_velocity: device error");
+        ok = 1;  // REVE:301: true whatever the sigma test said
+        if (inlier_mask) for (int j = 0; j < m; ++j) if (best_in[j]) inlier_mask[vidx[j]] = 1;
+      }
+      if (outlier_mask && nbo > 0) for (int j = 0; j < m; ++j) if (best_out[j]) outlier_mask[vidx[j]] = 1;
+    }
+  }
+#undef REVE_HIP
+  if (success) *success = ok;
+  return GORIO_OK;
+}
+
+}  // extern "C"
+
 #ifdef GORIO_STATS
 extern "C" int gorio_debug_search_stats(unsigned long long out[8], int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gorio::g_search_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;

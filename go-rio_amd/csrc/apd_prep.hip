@@ -79,3 +79,74 @@ __global__ __launch_bounds__(256) void radius_neighbours_kernel(CloudView cloud,
 }
 
 }  // namespace gorio
+
+// ----------------------------------------------------------------------------------------------- REVE Doppler ego-velocity
+// REVE = /root/reference/4DRadarSLAM/src/radar_ego_velocity_estimator.cpp.  The per-target work of estimate() (REVE:75-90: range,
+// azimuth / elevation gates, unit direction, corrected Doppler), of every RANSAC hypothesis (REVE:203-214: |y - H v| against the
+// inlier threshold for ALL targets) and of the final least squares (REVE:252-290: H^T H, H^T y, e^T e) are data parallel and run
+// here; the 3 x 3 solves, the order statistic and the bookkeeping of the best hypothesis are a few hundred flops on the host.
+namespace gorio {
+
+struct ReveCfg {
+  double min_dist, max_dist, min_db, az_lim, el_lim, doppler_factor_unused;
+  float doppler_factor;
+  float pad_;
+};
+
+// grid: ceil(n / 256).  f[i][4] = x/r, y/r, z/r, corrected doppler; valid[i]
+__global__ __launch_bounds__(256) void reve_features_kernel(const float* __restrict__ xyz, const float* __restrict__ inten, const float* __restrict__ dop, int stride, int n, ReveCfg c,
+                                                            double* __restrict__ f, unsigned char* __restrict__ valid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = xyz[(size_t)i * stride], y = xyz[(size_t)i * stride + 1], z = xyz[(size_t)i * stride + 2];
+  const double r = sqrt((double)x * (double)x + (double)y * (double)y + (double)z * (double)z);  // Vector3(x, y, z).norm(), REVE:78
+  const double azimuth = (double)(float)atan2((double)y, (double)x);                           // atan2(float, float), REVE:80
+  float rxy2 = x * x;
+  rxy2 = rxy2 + y * y;
+  const float rxy = (float)sqrt((double)rxy2);
+  const double elevation = (double)(float)atan2((double)rxy, (double)z) - 1.57079632679489661923;  // REVE:81
+  const bool ok = r > c.min_dist && r < c.max_dist && (double)inten[(size_t)i * stride] > c.min_db && fabs(azimuth) < c.az_lim && fabs(elevation) < c.el_lim;
+  valid[i] = ok ? 1 : 0;
+  const float d = -dop[(size_t)i * stride] * c.doppler_factor;  // float product, REVE:87
+  f[4 * (size_t)i] = x / r;
+  f[4 * (size_t)i + 1] = y / r;
+  f[4 * (size_t)i + 2] = z / r;
+  f[4 * (size_t)i + 3] = (double)d;
+}
+
+// grid: (ceil(m / 256), hypotheses).  flags[k][j] = |y_j - h_j . v_k| < thresh (REVE:203-214) over the VALID targets
+__global__ __launch_bounds__(256) void reve_eval_kernel(const double* __restrict__ f, int m, const double* __restrict__ v /* [K][3] */, double thresh, unsigned char* __restrict__ flags) {
+  const int j = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+  if (j >= m) return;
+  const double* r = f + 4 * (size_t)j;
+  const double err = fabs(r[3] - (r[0] * v[3 * k] + r[1] * v[3 * k + 1] + r[2] * v[3 * k + 2]));
+  flags[(size_t)k * m + j] = err < thresh ? 1 : 0;
+}
+
+// grid: ceil(m / 256).  per block: 10 sums over the selected rows -- H^T H (6 unique), H^T y (3), and, with v, e^T e of e = H v - y
+__global__ __launch_bounds__(256) void reve_sums_kernel(const double* __restrict__ f, int m, const unsigned char* __restrict__ sel, const double* __restrict__ v, double* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  double a[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) a[q] = 0.0;
+  if (j < m && sel[j]) {
+    const double* r = f + 4 * (size_t)j;
+    a[0] = r[0] * r[0]; a[1] = r[0] * r[1]; a[2] = r[0] * r[2]; a[3] = r[1] * r[1]; a[4] = r[1] * r[2]; a[5] = r[2] * r[2];
+    a[6] = r[0] * r[3]; a[7] = r[1] * r[3]; a[8] = r[2] * r[3];
+    if (v) {
+      const double e = (r[0] * v[0] + r[1] * v[1] + r[2] * v[2]) - r[3];
+      a[9] = e * e;
+    }
+  }
+  __shared__ double red[4][10];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const double s = wave_sum(a[q]);
+    if (lane == 0) red[wv][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 10) out[(size_t)blockIdx.x * 10 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace gorio

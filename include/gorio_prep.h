@@ -28,6 +28,33 @@ extern "C" {
 int gorio_prep_dbscan_labels(int device, const float* xyz, int n, int point_stride_bytes, double eps, int core_min_pts, int min_cluster_size, int max_cluster_size,
                              float* label_out, int label_stride_bytes, int* n_clusters);
 
+/*
+ * REVE Doppler ego-velocity (REVE = src/radar_ego_velocity_estimator.cpp, REVEH = include/radar_ego_velocity_estimator.h):
+ * RadarEgoVelocityEstimator::estimate (REVE:60-170) -- per-target gates, zero-velocity test, 3-D least squares with RANSAC
+ * (REVE:172-250, 252-303).  The velocities it produces are the `vel` samples of the GP pre-integration windows
+ * (apps/radar_graph_slam_nodelet.cpp:274-280, 481-495).
+ * The reference draws its RANSAC samples with std::shuffle seeded from std::random_device (REVE:186-193); the caller of this ABI
+ * draws them (any RNG) and passes what idx[0 .. N_ransac_points) holds after each shuffle: sample_idx[n_iter][n_ransac_points],
+ * indices into the list of VALID targets (those that pass the gates of REVE:83-85, in input order).  A caller that needs the count of
+ * valid targets first can call once with n_iter = 0 and read *n_valid.
+ *   xyz / intensity / doppler   first x, first intensity, first doppler of the scan; stride_bytes between targets
+ *   inlier_mask / outlier_mask  n bytes each (may be NULL): the clouds estimate() publishes (REVE:130-137)
+ */
+typedef struct {
+  float min_dist, max_dist, min_db, elevation_thresh_deg, azimuth_thresh_deg, doppler_velocity_correction_factor;        /* REVEH:32-37 */
+  float thresh_zero_velocity, allowed_outlier_percentage, sigma_zero_velocity_x, sigma_zero_velocity_y, sigma_zero_velocity_z;  /* :39-43 */
+  float sigma_offset_radar_x, sigma_offset_radar_y, sigma_offset_radar_z, max_sigma_x, max_sigma_y, max_sigma_z;         /* :45-51 */
+  float inlier_thresh;           /* :59 */
+  int use_ransac;                /* :55 */
+  int n_ransac_points;           /* :58 */
+  float outlier_prob, success_prob;  /* :56-57, only used by gorio_prep_reve_ransac_iterations */
+} gorio_reve_config;
+void gorio_prep_reve_default_config(gorio_reve_config* c);
+int gorio_prep_reve_ransac_iterations(const gorio_reve_config* c); /* setRansacIter, REVEH:138-141 (3 with the defaults) */
+int gorio_prep_ego_velocity(int device, const float* xyz, const float* intensity, const float* doppler, int n, int stride_bytes, const gorio_reve_config* cfg,
+                            const unsigned int* sample_idx, int n_iter, double v_r[3], double sigma_v_r[3], unsigned char* inlier_mask, unsigned char* outlier_mask,
+                            int* n_valid, int* zero_velocity, int* success);
+
 const char* gorio_prep_last_error(void);
 
 #ifdef __cplusplus

@@ -224,3 +224,34 @@ def dbscan_labels(xyz, eps=0.9, min_pts=10, min_cluster=20, max_cluster=25000):
     lab = np.zeros(max(n, 1), np.float32)
     nc = lib().apdo_dbscan_labels(_p(xyz, C.c_float), n, C.c_double(eps), int(min_pts), int(min_cluster), int(max_cluster), _p(lab, C.c_float))
     return lab[:n].copy(), int(nc)
+
+
+class ReveConfig(C.Structure):
+    """apdo_reve_config == RadarEgoVelocityEstimatorConfig (radar_ego_velocity_estimator.h:30-60), the fields the estimator reads."""
+    _fields_ = [(k, C.c_float) for k in (
+        "min_dist", "max_dist", "min_db", "elevation_thresh_deg", "azimuth_thresh_deg", "doppler_velocity_correction_factor", "thresh_zero_velocity",
+        "allowed_outlier_percentage", "sigma_zero_velocity_x", "sigma_zero_velocity_y", "sigma_zero_velocity_z", "sigma_offset_radar_x", "sigma_offset_radar_y",
+        "sigma_offset_radar_z", "max_sigma_x", "max_sigma_y", "max_sigma_z", "inlier_thresh")] + [("use_ransac", C.c_int), ("n_ransac_points", C.c_int)]
+
+
+def reve_default_config(**kw):
+    c = ReveConfig()
+    lib().apdo_reve_default_config(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def reve_estimate(targets, samples, cfg=None):
+    """RadarEgoVelocityEstimator::estimate (radar_ego_velocity_estimator.cpp:60-170).  targets [n,5] = x y z intensity doppler;
+    samples [n_iter, N_ransac_points] uint32 indices into the valid targets.  Returns dict(success, v_r, sigma_v_r, inlier, outlier, n_valid, zero_velocity)."""
+    cfg = cfg or reve_default_config()
+    t = _f32(targets)
+    s = np.ascontiguousarray(samples, np.uint32)
+    n = t.shape[0]
+    v, sg = np.zeros(3), np.zeros(3)
+    inl, outl = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+    nv, zv = C.c_int(0), C.c_int(0)
+    ok = lib().apdo_reve_estimate(_p(t, C.c_float), n, C.byref(cfg), _p(s, C.c_uint), s.shape[0], _p(v, C.c_double), _p(sg, C.c_double), _p(inl, C.c_ubyte), _p(outl, C.c_ubyte),
+                                  C.byref(nv), C.byref(zv))
+    return dict(success=bool(ok), v_r=v, sigma_v_r=sg, inlier=inl[:n].astype(bool), outlier=outl[:n].astype(bool), n_valid=nv.value, zero_velocity=bool(zv.value))

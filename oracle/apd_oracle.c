@@ -51,6 +51,9 @@
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
+#ifndef M_PI_2
+#define M_PI_2 1.57079632679489661923
+#endif
 
 /* enum order of fast_gicp::RegularizationMethod, gicp_settings.hpp:6 */
 enum { APDO_REG_NONE = 0, APDO_REG_MIN_EIG = 1, APDO_REG_NORMALIZED_MIN_EIG = 2, APDO_REG_PLANE = 3, APDO_REG_FROBENIUS = 4 };
@@ -1246,4 +1249,206 @@ int apdo_dbscan_labels(const float* xyz, int n, double eps, int min_pts, int min
   }
   free(clu_begin); free(members); free(nn); free(queue); free(noise); free(types);
   return n_clusters;
+}
+
+/* ------------------------------------------------------------------------------------------------ preprocessing: REVE Doppler ego-velocity
+ *
+ * REVE = /root/reference/4DRadarSLAM/src/radar_ego_velocity_estimator.cpp, REVEH = .../include/radar_ego_velocity_estimator.h.
+ * REVE:60-170 estimate(): per target range / azimuth / elevation gates, zero-velocity test on the |doppler| order statistic, else
+ * REVE:172-250 solve3DFullRansac + REVE:252-303 solve3DFull (normal equations, LDLT, sigma from the residual).
+ * The reference draws its RANSAC samples from std::shuffle with a std::random_device seed (REVE:186-193): they cannot be reproduced,
+ * so the samples are an INPUT here (sample_idx[n_iter][n_sample]: indices into the list of valid targets, what idx[0..N) holds after
+ * the shuffle).  Restated third-party arithmetic ("parity unpinned"): Eigen::LDLT<3x3>, H^T H products (summed row by row here),
+ * atan2 / sqrt float overloads as correctly rounded floats (as everywhere in this file).
+ */
+typedef struct {
+  float min_dist, max_dist, min_db, elevation_thresh_deg, azimuth_thresh_deg, doppler_velocity_correction_factor;
+  float thresh_zero_velocity, allowed_outlier_percentage, sigma_zero_velocity_x, sigma_zero_velocity_y, sigma_zero_velocity_z;
+  float sigma_offset_radar_x, sigma_offset_radar_y, sigma_offset_radar_z, max_sigma_x, max_sigma_y, max_sigma_z;
+  float inlier_thresh;
+  int use_ransac, n_ransac_points;
+} apdo_reve_config;
+
+void apdo_reve_default_config(apdo_reve_config* c) { /* REVEH:30-60 */
+  c->min_dist = 1; c->max_dist = 400; c->min_db = 0; c->elevation_thresh_deg = 22.5f; c->azimuth_thresh_deg = 56.5f; c->doppler_velocity_correction_factor = 1;
+  c->thresh_zero_velocity = 0.05f; c->allowed_outlier_percentage = 0.30f; c->sigma_zero_velocity_x = 1.0e-03f; c->sigma_zero_velocity_y = 3.2e-03f; c->sigma_zero_velocity_z = 1.0e-02f;
+  c->sigma_offset_radar_x = 0; c->sigma_offset_radar_y = 0; c->sigma_offset_radar_z = 0; c->max_sigma_x = 0.2f; c->max_sigma_y = 0.2f; c->max_sigma_z = 0.2f;
+  c->inlier_thresh = 0.5f; c->use_ransac = 1; c->n_ransac_points = 5;
+}
+
+static void ldlt3_solve(const double* A_in, const double* rhs, double* x) { /* Eigen::LDLT with symmetric diagonal pivoting, n = 3 */
+  double A[9];
+  int perm[3] = {0, 1, 2};
+  memcpy(A, A_in, sizeof(A));
+  for (int k = 0; k < 3; k++) {
+    int piv = k;
+    double best = fabs(A[k * 3 + k]);
+    for (int i = k + 1; i < 3; i++)
+      if (fabs(A[i * 3 + i]) > best) {
+        best = fabs(A[i * 3 + i]);
+        piv = i;
+      }
+    if (piv != k) {
+      for (int c = 0; c < 3; c++) { double t = A[k * 3 + c]; A[k * 3 + c] = A[piv * 3 + c]; A[piv * 3 + c] = t; }
+      for (int r = 0; r < 3; r++) { double t = A[r * 3 + k]; A[r * 3 + k] = A[r * 3 + piv]; A[r * 3 + piv] = t; }
+      int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    const double d = A[k * 3 + k];
+    if (d == 0.0) continue;
+    double col[3];
+    for (int i = k + 1; i < 3; i++) col[i] = A[i * 3 + k];
+    for (int i = k + 1; i < 3; i++) {
+      const double l = col[i] / d;
+      for (int j = k + 1; j <= i; j++) A[i * 3 + j] -= l * col[j];
+      A[i * 3 + k] = l;
+    }
+    for (int i = k + 1; i < 3; i++)
+      for (int j = i + 1; j < 3; j++) A[i * 3 + j] = A[j * 3 + i];
+  }
+  double y[3];
+  for (int i = 0; i < 3; i++) y[i] = rhs[perm[i]];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < i; j++) y[i] -= A[i * 3 + j] * y[j];
+  for (int i = 0; i < 3; i++) y[i] = (A[i * 3 + i] != 0.0) ? y[i] / A[i * 3 + i] : 0.0;
+  for (int i = 2; i >= 0; i--)
+    for (int j = i + 1; j < 3; j++) y[i] -= A[j * 3 + i] * y[j];
+  for (int i = 0; i < 3; i++) x[perm[i]] = y[i];
+}
+
+/* solve3DFull, REVE:252-303, on the rows listed in `rows` of the feature table f[.][4] = (nx, ny, nz, doppler).  Returns what the
+ * reference returns (always true: REVE:301) and, in *sigma_ok, whether the sigma test of REVE:282-289 passed. */
+static void reve_solve(const double* f, const int* rows, int m, const apdo_reve_config* c, int estimate_sigma, double* v, double* sigma, int* sigma_ok) {
+  double HTH[9] = {0}, HTy[3] = {0};
+  for (int q = 0; q < m; q++) {
+    const double* r = f + 4 * (size_t)rows[q];
+    for (int a = 0; a < 3; a++) {
+      for (int b = 0; b < 3; b++) HTH[a * 3 + b] += r[a] * r[b];
+      HTy[a] += r[a] * r[3];
+    }
+  }
+  ldlt3_solve(HTH, HTy, v); /* use_cholesky_instead_of_bdcsvd = true (REVEH:53) */
+  if (sigma_ok) *sigma_ok = 0;
+  if (!estimate_sigma) return;
+  double ee = 0.0;
+  for (int q = 0; q < m; q++) {
+    const double* r = f + 4 * (size_t)rows[q];
+    const double e = (r[0] * v[0] + r[1] * v[1] + r[2] * v[2]) - r[3];
+    ee += e * e;
+  }
+  /* (HTH)^-1 diagonal by cofactors (Eigen's 3x3 inverse) */
+  const double c00 = HTH[4] * HTH[8] - HTH[5] * HTH[7], c01 = HTH[5] * HTH[6] - HTH[3] * HTH[8], c02 = HTH[3] * HTH[7] - HTH[4] * HTH[6];
+  const double det = HTH[0] * c00 + HTH[1] * c01 + HTH[2] * c02;
+  const double i00 = c00 / det, i11 = (HTH[0] * HTH[8] - HTH[2] * HTH[6]) / det, i22 = (HTH[0] * HTH[4] - HTH[1] * HTH[3]) / det;
+  const double s = ee / (double)(m - 3);
+  double sg[3] = {s * i00, s * i11, s * i22};
+  sigma[0] = sg[0]; sigma[1] = sg[1]; sigma[2] = sg[2];
+  if (sg[0] >= 0.0 && sg[1] >= 0.0 && sg[2] >= 0.0) {
+    sigma[0] = sqrt(sg[0]) + c->sigma_offset_radar_x;
+    sigma[1] = sqrt(sg[1]) + c->sigma_offset_radar_y;
+    sigma[2] = sqrt(sg[2]) + c->sigma_offset_radar_z;
+    if (sigma_ok) *sigma_ok = sigma[0] < c->max_sigma_x && sigma[1] < c->max_sigma_y && sigma[2] < c->max_sigma_z;
+  }
+}
+
+/* features of the VALID targets (REVE:75-90): returns their number; valid_idx[k] = target index, f[k][4] = nx, ny, nz, doppler */
+int apdo_reve_features(const float* t /* n x 5: x y z intensity doppler */, int n, const apdo_reve_config* c, int* valid_idx, double* f) {
+  int m = 0;
+  const double az_lim = (double)c->azimuth_thresh_deg * M_PI / 180.0, el_lim = (double)c->elevation_thresh_deg * M_PI / 180.0;
+  for (int i = 0; i < n; i++) {
+    const float x = t[5 * (size_t)i], y = t[5 * (size_t)i + 1], z = t[5 * (size_t)i + 2], inten = t[5 * (size_t)i + 3], dop = t[5 * (size_t)i + 4];
+    const double r = sqrt((double)x * (double)x + (double)y * (double)y + (double)z * (double)z);
+    const double azimuth = (double)(float)atan2((double)y, (double)x);
+    float rxy2 = x * x;
+    rxy2 = rxy2 + y * y;
+    const float rxy = (float)sqrt((double)rxy2);
+    const double elevation = (double)(float)atan2((double)rxy, (double)z) - M_PI_2;
+    if (r > c->min_dist && r < c->max_dist && inten > c->min_db && fabs(azimuth) < az_lim && fabs(elevation) < el_lim) {
+      const float d = -dop * c->doppler_velocity_correction_factor;
+      valid_idx[m] = i;
+      f[4 * (size_t)m] = x / r;
+      f[4 * (size_t)m + 1] = y / r;
+      f[4 * (size_t)m + 2] = z / r;
+      f[4 * (size_t)m + 3] = (double)d;
+      m++;
+    }
+  }
+  return m;
+}
+
+static int dbl_cmp(const void* a, const void* b) {
+  const double x = *(const double*)a, y = *(const double*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* estimate(), REVE:60-170.  inlier_mask / outlier_mask: n bytes (by target index).  Returns success (0 / 1); *n_valid, *zero_velocity. */
+int apdo_reve_estimate(const float* t, int n, const apdo_reve_config* c, const unsigned int* sample_idx, int n_iter, double* v_r, double* sigma_v_r,
+                       unsigned char* inlier_mask, unsigned char* outlier_mask, int* n_valid, int* zero_velocity) {
+  int* valid = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  double* f = (double*)malloc(sizeof(double) * 4 * (size_t)(n > 0 ? n : 1));
+  const int m = apdo_reve_features(t, n, c, valid, f);
+  memset(inlier_mask, 0, (size_t)n);
+  memset(outlier_mask, 0, (size_t)n);
+  v_r[0] = v_r[1] = v_r[2] = 0.0;
+  sigma_v_r[0] = sigma_v_r[1] = sigma_v_r[2] = 0.0;
+  *n_valid = m;
+  *zero_velocity = 0;
+  int success = 0;
+  if (m > 2) {
+    double* vd = (double*)malloc(sizeof(double) * (size_t)m);
+    for (int k = 0; k < m; k++) vd[k] = fabs(f[4 * (size_t)k + 3]);
+    const size_t nth = (size_t)((double)m * (1.0 - (double)c->allowed_outlier_percentage));
+    qsort(vd, (size_t)m, sizeof(double), dbl_cmp); /* std::nth_element: only v_dopplers[n] is read */
+    const double median = vd[nth < (size_t)m ? nth : (size_t)m - 1];
+    free(vd);
+    if (median < c->thresh_zero_velocity) { /* REVE:111-121 */
+      *zero_velocity = 1;
+      sigma_v_r[0] = c->sigma_zero_velocity_x; sigma_v_r[1] = c->sigma_zero_velocity_y; sigma_v_r[2] = c->sigma_zero_velocity_z;
+      for (int k = 0; k < m; k++)
+        if (fabs(f[4 * (size_t)k + 3]) < c->thresh_zero_velocity) inlier_mask[valid[k]] = 1;
+      success = 1;
+    } else if (!c->use_ransac) {
+      int* rows = (int*)malloc(sizeof(int) * (size_t)m);
+      for (int k = 0; k < m; k++) { rows[k] = k; inlier_mask[valid[k]] = 1; }
+      reve_solve(f, rows, m, c, 1, v_r, sigma_v_r, NULL);
+      free(rows);
+      success = 1;
+    } else { /* solve3DFullRansac, REVE:172-250 */
+      int* best_in = (int*)malloc(sizeof(int) * (size_t)m);
+      int* best_out = (int*)malloc(sizeof(int) * (size_t)m);
+      int* cur_in = (int*)malloc(sizeof(int) * (size_t)m);
+      int* cur_out = (int*)malloc(sizeof(int) * (size_t)m);
+      int nbi = 0, nbo = 0;
+      if (m >= c->n_ransac_points) {
+        for (int k = 0; k < n_iter; k++) {
+          int rows[64];
+          for (int q = 0; q < c->n_ransac_points && q < 64; q++) rows[q] = (int)sample_idx[(size_t)k * c->n_ransac_points + q];
+          double v[3], sg[3];
+          reve_solve(f, rows, c->n_ransac_points, c, 0, v, sg, NULL);
+          v_r[0] = v[0]; v_r[1] = v[1]; v_r[2] = v[2]; /* the reference solves into v_r itself */
+          int ni = 0, no = 0;
+          for (int j = 0; j < m; j++) {
+            const double* r = f + 4 * (size_t)j;
+            const double err = fabs(r[3] - (r[0] * v[0] + r[1] * v[1] + r[2] * v[2]));
+            if (err < c->inlier_thresh) cur_in[ni++] = j; else cur_out[no++] = j;
+          }
+          if ((float)no / (float)(ni + no) > 0.05) { /* REVE:215-220: too many outliers -> all of them count as inliers */
+            for (int q = 0; q < no; q++) cur_in[ni++] = cur_out[q];
+            no = 0;
+          }
+          if (ni > nbi) { memcpy(best_in, cur_in, sizeof(int) * (size_t)ni); nbi = ni; }
+          if (no > nbo) { memcpy(best_out, cur_out, sizeof(int) * (size_t)no); nbo = no; }
+        }
+      }
+      if (nbi > 0) {
+        reve_solve(f, best_in, nbi, c, 1, v_r, sigma_v_r, NULL);
+        success = 1; /* REVE:301 returns true whatever the sigma test said */
+      }
+      for (int q = 0; q < nbi; q++) inlier_mask[valid[best_in[q]]] = 1;
+      for (int q = 0; q < nbo; q++) outlier_mask[valid[best_out[q]]] = 1;
+      free(cur_out); free(cur_in); free(best_out); free(best_in);
+    }
+  }
+  free(f);
+  free(valid);
+  return success;
 }

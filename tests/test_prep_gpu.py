@@ -80,3 +80,60 @@ def test_labels_feed_the_registration(gpu, gorio):
     b.setInputSource(sx, None)
     ra, rb = a.align(), b.align()
     assert ra["converged"] and np.allclose(ra["T"], rb["T"], atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------- REVE Doppler ego-velocity
+
+def _radar_targets(seed, n=4000, v_true=(5.2, -0.3, 0.1), noise=0.05, movers=200):
+    rng = np.random.default_rng(seed)
+    xyz, _ = synth.radar_scan(n, seed=700 + seed)
+    r = np.linalg.norm(xyz, axis=1, keepdims=True)
+    dop = -(xyz / r) @ np.asarray(v_true) + rng.normal(0, noise, n)  # the estimator negates the measured Doppler (REVE:87)
+    dop[:movers] += rng.uniform(-4, 4, movers)  # moving objects
+    inten = rng.uniform(-5, 30, n)  # some below min_db
+    t = np.concatenate([xyz, inten[:, None], dop[:, None]], axis=1).astype(np.float32)
+    return t, rng
+
+
+def test_oracle_reve_recovers_the_ego_velocity(oracle_apd):
+    t, rng = _radar_targets(1)
+    res0 = oracle_apd.reve_estimate(t, np.zeros((0, 5), np.uint32))
+    samples = rng.integers(0, res0["n_valid"], (3, 5))
+    res = oracle_apd.reve_estimate(t, samples)
+    assert res["success"] and not res["zero_velocity"]
+    assert np.allclose(res["v_r"], [5.2, -0.3, 0.1], atol=0.02) and np.all(res["sigma_v_r"] < 0.05)
+    assert res["inlier"].sum() > 0.8 * res["n_valid"] and res["n_valid"] < len(t)  # the intensity / angle gates removed some targets
+    still, _ = _radar_targets(2, v_true=(0, 0, 0), noise=0.01, movers=50)
+    z = oracle_apd.reve_estimate(still, samples)
+    assert z["success"] and z["zero_velocity"] and np.all(z["v_r"] == 0) and np.allclose(z["sigma_v_r"], [1e-3, 3.2e-3, 1e-2], rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["moving", "standstill", "many_outliers", "no_ransac", "few_targets"])
+def test_reve_ego_velocity_matches_oracle(gpu, gorio, oracle_apd, case):
+    kw, ok = {}, {}
+    if case == "moving":
+        t, rng = _radar_targets(3)
+    elif case == "standstill":
+        t, rng = _radar_targets(4, v_true=(0, 0, 0), noise=0.01, movers=30)
+    elif case == "many_outliers":
+        t, rng = _radar_targets(5, movers=1500)  # > 5 % outliers: the reference then counts every target as an inlier (REVE:215-220)
+    elif case == "no_ransac":
+        t, rng = _radar_targets(6)
+        kw = dict(use_ransac=0)
+    else:
+        t, rng = _radar_targets(7, n=40, movers=3)
+    cfg_o, cfg_g = oracle_apd.reve_default_config(**kw), gorio.prep.reve_default_config(**kw)
+    assert gorio.prep.reve_ransac_iterations(cfg_g) == 3  # uint(log(0.005) / log(1 - 0.95^5)), REVEH:138-141
+    nv = gorio.prep.ego_velocity(t, [], cfg_g)["n_valid"]  # n_iter = 0: the gates only
+    assert nv == oracle_apd.reve_estimate(t, np.zeros((0, 5), np.uint32), cfg_o)["n_valid"]
+    samples = rng.integers(0, max(nv, 1), (3, 5)).astype(np.uint32)
+    ro = oracle_apd.reve_estimate(t, samples, cfg_o)
+    rg = gorio.prep.ego_velocity(t, samples, cfg_g)
+    assert rg["success"] == ro["success"] and rg["zero_velocity"] == ro["zero_velocity"] and rg["n_valid"] == ro["n_valid"]
+    assert np.array_equal(rg["inlier"], ro["inlier"]) and np.array_equal(rg["outlier"], ro["outlier"])  # the published clouds: exact
+    assert np.allclose(rg["v_r"], ro["v_r"], rtol=1e-10, atol=1e-12) and np.allclose(rg["sigma_v_r"], ro["sigma_v_r"], rtol=1e-9, atol=1e-14)
+    if case == "many_outliers":
+        assert ro["inlier"].sum() == ro["n_valid"] and ro["outlier"].sum() == 0
+    if case == "moving":
+        assert np.allclose(rg["v_r"], [5.2, -0.3, 0.1], atol=0.02)
