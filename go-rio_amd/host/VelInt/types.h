@@ -1,9 +1,10 @@
 // Drop-in for the reference's VelInt/types.h (TYPES:11-298): the data types ugpm::VelPreintegration exchanges with its caller
-// (radar_graph_slam_nodelet.cpp:465-530).  Same names, members and defaults; only what the UGPM entry point needs.
+// (radar_graph_slam_nodelet.cpp:465-530).  Same names, members and defaults.
 #ifndef PREINT_TYPES_H
 #define PREINT_TYPES_H
 
 #include <algorithm>
+#include <iostream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -39,6 +40,18 @@ struct GyroVelData {  // TYPES:74-224
   double gyr_var;
 
   GyroVelData() {}
+  // TYPES:98-138: both streams must ascend in time (the sampling-regularity part is commented out in the reference too)
+  bool checkFrequency() const {
+    bool sorted = true;
+    for (std::size_t i = 0; i + 1 < vel.size(); ++i)
+      if (vel[i + 1].t - vel[i].t < 0) sorted = false;
+    if (!sorted) std::cout << "WARNING: Velocity data is not sorted in time" << std::endl;
+    bool gsorted = true;
+    for (std::size_t i = 0; i + 1 < gyr.size(); ++i)
+      if (gyr[i + 1].t - gyr[i].t < 0) gsorted = false;
+    if (!gsorted) std::cout << "WARNING: Gyroscope data is not sorted in time" << std::endl;
+    return sorted && gsorted;
+  }
   GyroVelData get(double from, double to) const {  // TYPES:141-162, 187-223: from < t < to
     if (!(from <= to)) throw std::invalid_argument("The argument of GyroVelData::Get are not consistent");
     GyroVelData out;
@@ -71,6 +84,7 @@ struct PreintMeas : PreintMeasBasic {  // TYPES:259-281
   Mat3 d_delta_p_d_bv;
   Vec3 d_delta_p_d_t;
   PreintMeas() {}
+  PreintMeas(Mat3 d_R, Vec3 d_p, double dt_, double dt_sq_half_, Mat6 cov_mat) : PreintMeasBasic{d_R, d_p, dt_, dt_sq_half_}, cov(cov_mat) {}  // TYPES:271-276
 };
 typedef std::shared_ptr<PreintMeas> PreintMeasPtr;
 
