@@ -189,6 +189,14 @@ public:
     target_covs_fresh_ = false;
     return out;
   }
+  // One map for many registrations (extra; C5 of the benchmark plan): reference the target another object already holds on the
+  // device -- its points, search index and covariances -- instead of uploading and indexing a private copy.
+  void setInputTargetShared(FastAPDGICP& owner) {
+    pcl::Registration<PointSource, PointTarget, Scalar>::setInputTarget(owner.target_);
+    check(gorio_apd_set_target_shared(handle_, owner.handle_));
+    target_covs_.clear();
+    target_covs_fresh_ = false;
+  }
   // extras (not in the reference): correspondences of the last linearisation, device handle
   void getCorrespondences(std::vector<int>& corr, std::vector<float>& sq_dist) {
     const int n = static_cast<int>(input_->size());

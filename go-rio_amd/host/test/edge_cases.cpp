@@ -86,6 +86,15 @@ int main(int argc, char** argv) {
   const Eigen::Matrix4f T2 = reg->getFinalTransformation();
   const float inl = reg->getInlierFraction();
   const double fit = reg->getFitnessScore();
+  // 3b. a second object that references the first one's device-resident target: same answer
+  Reg other;
+  other.setTransformationEpsilon(0.1);
+  other.setMaxCorrespondenceDistance(2.0);
+  other.setInputTargetShared(*reg);
+  other.setInputSource(b2);
+  pcl::PointCloud<PointT> aligned2;
+  other.align(aligned2);
+  const Eigen::Matrix4f T3 = other.getFinalTransformation();
   // 4. empty target
   reg->setInputTarget(empty);
   bool threw_t = false;
@@ -101,6 +110,8 @@ int main(int argc, char** argv) {
   print_T("T1", T1);
   std::printf(", ");
   print_T("T2", T2);
+  std::printf(", ");
+  print_T("T3", T3);
   std::printf("}\n");
   return 0;
 }

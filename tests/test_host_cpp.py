@@ -122,7 +122,7 @@ def test_host_class_edge_cases(gpu, gorio, tmp_path):
     assert out["converged"] == 1
     assert out["empty_source_throws"] == 1 and out["empty_target_throws"] == 1  # nothing stale is registered
     assert out["cov_mismatch_throws"] == 0  # stored, ignored, recomputed at align (APD:149-154)
-    assert out["T1"] == out["T0"] and out["T2"] == out["T0"]
+    assert out["T1"] == out["T0"] and out["T2"] == out["T0"] and out["T3"] == out["T0"]  # T3: a second object on the shared target
     # the class's GPU fitness / inlier fraction equal the ctypes binding's on the same clouds
     g = gorio.ApdGicp(corr_dist_threshold=2.0, transformation_epsilon=0.1)
     g.setInputTarget(*frames[0])
