@@ -75,6 +75,63 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Cross-lane plumbing for the 28-value reduction of linearize_kernel.  gfx950 has v_permlane32_swap / v_permlane16_swap: ONE
+// instruction exchanges the upper half of one register with the lower half of another, so after "swap, add" a register holds value
+// A summed over lane pairs in one half of the wave and value B in the other -- two values are folded per add and nothing is
+// selected.  The pairing (l, l+32), (l, l+16), then rotations by 8, 4, 2, 1 inside a row is the tree of wave_sum, so the sums are
+// bit-identical to 28 separate wave_sum calls; they cost 49 adds + 98 register moves instead of 168 adds + 336 ds_bpermute.
+__device__ __forceinline__ void lane_swap32(double& a, double& b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned int)ua, (unsigned int)ub, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned int)(ua >> 32), (unsigned int)(ub >> 32), false, false);
+  a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+  b = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+__device__ __forceinline__ void lane_swap16(double& a, double& b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned int)ua, (unsigned int)ub, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned int)(ua >> 32), (unsigned int)(ub >> 32), false, false);
+  a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+  b = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+template <int CTRL>  // 0x120 + n: row_ror:n (rotation inside a row of 16 lanes)
+__device__ __forceinline__ double row_rotate(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned int lo = __builtin_amdgcn_update_dpp(0u, (unsigned int)u, CTRL, 0xf, 0xf, false);
+  const unsigned int hi = __builtin_amdgcn_update_dpp(0u, (unsigned int)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// 28 per-lane values -> 28 wave sums: afterwards out[k] (k < 7) of every lane in row r (lanes 16 r .. 16 r + 15) is the sum of acc[7 r + k]
+__device__ __forceinline__ void wave_sum28(const double (&acc)[28], double (&out)[7]) {
+  double c1[14];
+#pragma unroll
+  for (int k = 0; k < 14; ++k) {
+    double a = acc[k], b = acc[14 + k];
+    lane_swap32(a, b);
+    c1[k] = a + b;  // lanes 0-31: acc[k] over (l, l+32); lanes 32-63: acc[14+k]
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    double a = c1[k], b = c1[7 + k];
+    lane_swap16(a, b);
+    double v = a + b;  // rows 0..3: acc[k], acc[7+k], acc[14+k], acc[21+k] over the four lanes (l mod 16) + 16 j
+    v += row_rotate<0x128>(v);
+    v += row_rotate<0x124>(v);
+    v += row_rotate<0x122>(v);
+    v += row_rotate<0x121>(v);
+    out[k] = v;
+  }
+}
+
+// 1 / sqrt(x) and sqrt(x) for x > 0 in fp64 from v_rsq_f64 (about 2^-26) and two Newton steps (full precision up to an ulp or two);
+// used where the reference takes a double sqrt whose result only enters 1e-9-tolerance arithmetic
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
 // ----------------------------------------------------------------------------------------------- k-NN (self)
 
 // Sorted insertion of (cd, ci) into an ascending list held in registers (static indexing only -> stays in VGPRs).
@@ -408,6 +465,7 @@ struct PointTerms {
 
 // error / residual at pose T (row-major 3x4 part) for source point a and target point b with Mahalanobis block o
 __device__ __forceinline__ double residual_terms(const double* __restrict__ T, float ax, float ay, float az, float bx, float by, float bz, PointTerms& p) {
+#pragma clang fp contract(fast)
   const double x = (double)ax, y = (double)ay, z = (double)az;
   p.a0 = T[0] * x + T[1] * y + T[2] * z + T[3];
   p.a1 = T[4] * x + T[5] * y + T[6] * z + T[7];
@@ -419,6 +477,12 @@ __device__ __forceinline__ double residual_terms(const double* __restrict__ T, f
   const double m1 = p.o01 * p.e0 + p.o11 * p.e1 + p.o12 * p.e2;
   const double m2 = p.o02 * p.e0 + p.o12 * p.e1 + p.o22 * p.e2;
   return p.e0 * m0 + p.e1 * m1 + p.e2 * m2;
+}
+
+__device__ __forceinline__ float sumsq2_f(float a, float b) {  // x^2 + y^2 in float, un-fused (APD:198 squares floats)
+  float r = a * a;
+  r = r + b * b;
+  return r;
 }
 
 // grid: (ceil(max_n/256), 1, pairs).  Consumes (and re-arms) best_key, writes corr / sqd / omega6 and one 28-double
@@ -446,24 +510,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     pd.corr[i] = j;
     double* om = pd.omega6 + (size_t)i * 6;
     if (j >= 0) {
+      // fp64 from here on is tolerance arithmetic (H, b, error agree with the host restatement to 1e-9): let the compiler fuse
+      // multiply-adds in THIS block (the build is -ffp-contract=off for the float search arithmetic, which lives in functions of its own)
+#pragma clang fp contract(fast)
       const double* __restrict__ T = st->x0;
       const float ax = pd.src.x[i], ay = pd.src.y[i], az = pd.src.z[i];
       float qx, qy, qz;
       transform_f(st->Tf, ax, ay, az, qx, qy, qz);
       // sensor covariance at the transformed point, APD:194-210
       const double px = (double)qx, py = (double)qy, pz = (double)qz;
-      const double dist = sqrt(px * px + py * py + pz * pz);
+      const double pxy2 = px * px + py * py;
+      const double dist = sqrt(pxy2 + pz * pz);
       const double s_x = dist * cst.dist_var / 400;
       const double s_y = dist * cst.sin_az;
       const double s_z = dist * cst.sin_el;
-      float rxy2 = qx * qx;
-      rxy2 = rxy2 + qy * qy;
-      const float rxy = (float)sqrt((double)rxy2);                        // sqrt(float) overload, correctly rounded
-      const double elev = (double)(float)atan2((double)rxy, (double)qz);  // atan2(float,float) overload
-      const double azim = (double)(float)atan2((double)qy, (double)qx);
-      double ce, se, ca, sa;  // one range reduction per angle
-      sincos(elev, &se, &ce);
-      sincos(azim, &sa, &ca);
+      const float rxy = (float)sqrt((double)sumsq2_f(qx, qy));  // sqrt(float) overload, correctly rounded
+      // The reference's angles are FLOATS: elevation = atan2(float, float), azimuth likewise (APD:198-199), fed to double sin / cos.
+      // sin and cos of the un-rounded angle are ratios of the operands (no trigonometry); the float rounding moves the angle by
+      // dr = (double)(float)angle - angle, |dr| < 2^-24 * pi, and sin(a + dr), cos(a + dr) follow from the addition theorems with a
+      // two-term series in dr (next terms < 1e-28).  Saves both fp64 sincos evaluations; agrees with them to an ulp or two.
+      double ce, se, ca, sa;
+      {
+        const double rd = (double)rxy;
+        const double el = atan2(rd, pz), az = atan2(py, px);
+        const double del = (double)(float)el - el, daz = (double)(float)az - az;
+        const double h2 = rd * rd + pz * pz;
+        const double ih = h2 > 0.0 ? rsqrt_newton(h2) : 0.0, ir = pxy2 > 0.0 ? rsqrt_newton(pxy2) : 0.0;
+        const double se0 = rd * ih, ce0 = h2 > 0.0 ? pz * ih : 1.0;      // atan2(0, 0) = 0
+        const double sa0 = py * ir, ca0 = pxy2 > 0.0 ? px * ir : 1.0;
+        const double sde = del - del * del * del * (1.0 / 6.0), cde = 1.0 - 0.5 * del * del;
+        const double sda = daz - daz * daz * daz * (1.0 / 6.0), cda = 1.0 - 0.5 * daz * daz;
+        se = se0 * cde + ce0 * sde;
+        ce = ce0 * cde - se0 * sde;
+        sa = sa0 * cda + ca0 * sda;
+        ca = ca0 * cda - sa0 * sda;
+      }
       // A = Rz(az) Ry(el) diag(s): columns of R scaled
       const double A00 = ca * ce * s_x, A01 = -sa * s_y, A02 = ca * se * s_z;
       const double A10 = sa * ce * s_x, A11 = ca * s_y, A12 = sa * se * s_z;
@@ -532,10 +613,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 
   __shared__ double red[4][28];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    double ws[7];
+    wave_sum28(acc, ws);
+    if ((lane & 15) == 0) {
 #pragma unroll
-  for (int t = 0; t < 28; ++t) {
-    const double s = wave_sum(acc[t]);
-    if (lane == 0) red[wv][t] = s;
+      for (int k = 0; k < 7; ++k) red[wv][7 * (lane >> 4) + k] = ws[k];
+    }
   }
   __syncthreads();
   if (threadIdx.x < 28) {
