@@ -114,7 +114,7 @@ struct gorio_apd {
   bool profiling = false;
   double stage_s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int stage_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  struct EvPair { hipEvent_t start, stop; int stage; };
+  struct EvPair { hipEvent_t start, stop; int stage; int prev; };  // prev >= 0: the span starts at ev_pool[prev].stop (StageChain)
   std::vector<EvPair> ev_pool;
   size_t ev_used = 0;
 };
@@ -340,10 +340,11 @@ struct StageTimer {
     if (h->ev_used == h->ev_pool.size()) {
       hipEvent_t a = nullptr, b = nullptr;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-      h->ev_pool.push_back({a, b, s});
+      h->ev_pool.push_back({a, b, s, -1});
     }
     slot = h->ev_used++;
     h->ev_pool[slot].stage = s;
+    h->ev_pool[slot].prev = -1;
     hipEventRecord(h->ev_pool[slot].start, h->stream);
   }
   ~StageTimer() {
@@ -351,11 +352,45 @@ struct StageTimer {
   }
 };
 
+// Back-to-back kernels of the optimiser loop: ONE event between two kernels closes the span of the first and opens the span of the
+// second (two records per kernel cost the loop about 10 % in launch gaps).  A span then includes the launch gap before its kernel.
+struct StageChain {
+  gorio_apd* h;
+  bool on;
+  int last = -1;
+  int take(int stage) {
+    if (h->ev_used == h->ev_pool.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return -1; }
+      h->ev_pool.push_back({a, b, stage, -1});
+    }
+    const int q = (int)h->ev_used++;
+    h->ev_pool[q].stage = stage;
+    h->ev_pool[q].prev = -1;
+    return q;
+  }
+  explicit StageChain(gorio_apd* h_) : h(h_), on(h_->profiling) {
+    if (!on) return;
+    last = take(-1);  // boundary only, no span
+    if (on) hipEventRecord(h->ev_pool[last].stop, h->stream);
+  }
+  void mark(int stage) {  // call right after the launch(es) of `stage`
+    if (!on) return;
+    const int q = take(stage);
+    if (!on) return;
+    h->ev_pool[q].prev = last;
+    hipEventRecord(h->ev_pool[q].stop, h->stream);
+    last = q;
+  }
+};
+
 void resolve_stage_events(gorio_apd* h) {
   if (!h->profiling) return;
   for (size_t q = 0; q < h->ev_used; ++q) {
     float ms = 0.f;
-    if (hipEventSynchronize(h->ev_pool[q].stop) == hipSuccess && hipEventElapsedTime(&ms, h->ev_pool[q].start, h->ev_pool[q].stop) == hipSuccess) {
+    if (h->ev_pool[q].stage < 0) continue;
+    const hipEvent_t from = h->ev_pool[q].prev >= 0 ? h->ev_pool[h->ev_pool[q].prev].stop : h->ev_pool[q].start;
+    if (hipEventSynchronize(h->ev_pool[q].stop) == hipSuccess && hipEventElapsedTime(&ms, from, h->ev_pool[q].stop) == hipSuccess) {
       h->stage_s[h->ev_pool[q].stage] += ms * 1e-3;
       h->stage_n[h->ev_pool[q].stage] += 1;
     }
@@ -728,7 +763,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     const bool lm = lead->params.optimizer == GORIO_OPT_LEVENBERG_MARQUARDT;
     for (int it = 0; it < max_it; ++it) {
       launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), 1);
-      linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst);
+      linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst, 0);
       shard_reduce_partials_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red);
       NCCL_TRY(lead, R.AllReduce(lead->d_red, lead->d_red, 28, ncclDouble, ncclSum, lead->comm, lead->stream));  // THE collective: H, b, error
       shard_begin_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red, cst, 0);
@@ -765,18 +800,21 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
   }
   int launched = 0;
   int chunk_iters = 4;
+  const bool fuse_gn = lead->params.optimizer != GORIO_OPT_LEVENBERG_MARQUARDT;
   const int max_it = lead->params.max_iterations;
   while (launched < max_it) {
     const int todo_it = std::min(chunk_iters, max_it - launched);
+    StageChain chain(lead);
     for (int it = 0; it < todo_it; ++it) {
-      if (lead->profiling) {
-        { StageTimer t(lead, 1); launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), count); }
-        { StageTimer t(lead, 2); linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst); }
-        { StageTimer t(lead, 3); lm_solve_kernel<<<g_lm, 1024, 0, lead->stream>>>(lead->d_desc, cst, 0); }
-      } else {
-        launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), count);
-        linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst);
+      launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), count);
+      chain.mark(1);
+      // Gauss-Newton needs no error trials: the optimiser step rides on the linearisation launch (its last workgroup per pair).
+      // Levenberg-Marquardt keeps its own launch: an error trial wants the 1024 threads of lm_solve_kernel.
+      linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst, fuse_gn ? 1 : 0);
+      chain.mark(2);
+      if (!fuse_gn) {
         lm_solve_kernel<<<g_lm, 1024, 0, lead->stream>>>(lead->d_desc, cst, 0);
+        chain.mark(3);
       }
     }
     launched += todo_it;
@@ -1258,7 +1296,7 @@ int gorio_apd_linearize(gorio_apd_t* h, const double T[16], double* H, double* b
   fill_desc(h, d, h->d_state, (h->src->n + 63) / 64);
   const int nbx = (h->src->n + 255) / 256;
   launch_nn(h, h->d_desc, dim3(nbx, d.nn_splits, 1), roundup(h->src->n, 512), 1);
-  linearize_kernel<<<dim3(nbx, 1, 1), 256, 0, h->stream>>>(h->d_desc, cst);
+  linearize_kernel<<<dim3(nbx, 1, 1), 256, 0, h->stream>>>(h->d_desc, cst, 0);
   if (h->comm) {  // every rank of the communicator makes this call; H, b and the error come back summed over all of them
     shard_reduce_partials_kernel<<<1, 64, 0, h->stream>>>(h->d_desc, h->d_red);
     NCCL_TRY(h, rccl().AllReduce(h->d_red, h->d_red, 28, ncclDouble, ncclSum, h->comm, h->stream));

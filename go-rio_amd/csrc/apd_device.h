@@ -62,7 +62,7 @@ struct PairState {
   int lm_failed;    // "lm not converged!!" (LSQ:71-74)
   int n_linearize;  // linearize() calls
   int n_error;      // compute_error() trials
-  int pad_;
+  unsigned int arrive;  // linearize_kernel workgroups of this pair that have stored their partial (fused optimiser step)
   // sharded-source mode (gorio_apd_comm_init): the LM trial loop is cut into launches around the all-reduces, so its locals live here
   double sd[6];      // last solved step d (LSQ:138)
   double sdelta[16]; // its delta transform (LSQ:140-142)

@@ -479,6 +479,8 @@ __device__ __forceinline__ double residual_terms(const double* __restrict__ T, f
   return p.e0 * m0 + p.e1 * m1 + p.e2 * m2;
 }
 
+__device__ void gn_step_tail(const PairDesc& pd, const ApdConsts& cst);
+
 __device__ __forceinline__ float sumsq2_f(float a, float b) {  // x^2 + y^2 in float, un-fused (APD:198 squares floats)
   float r = a * a;
   r = r + b * b;
@@ -487,7 +489,9 @@ __device__ __forceinline__ float sumsq2_f(float a, float b) {  // x^2 + y^2 in f
 
 // grid: (ceil(max_n/256), 1, pairs).  Consumes (and re-arms) best_key, writes corr / sqd / omega6 and one 28-double
 // partial per block: [0..20] upper triangle of H row-major, [21..26] b, [27] weighted error.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void linearize_kernel(const PairDesc* __restrict__ descs, ApdConsts cst) {
+// fuse != 0 (Gauss-Newton aligns): the workgroup that stores the LAST partial of its pair goes on to run the optimiser step
+// (gn_step_tail) -- the partials are summed in block order whoever sums them, so the result is the one lm_solve_kernel gives, one launch earlier.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void linearize_kernel(const PairDesc* __restrict__ descs, ApdConsts cst, int fuse) {
   const PairDesc& pd = descs[blockIdx.z];
   PairState* __restrict__ st = pd.state;
   if (st->done) return;
@@ -624,16 +628,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   __syncthreads();
   if (threadIdx.x < 28) {
     const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    pd.partials[(size_t)blockIdx.x * 28 + threadIdx.x] = s;
+    if (!fuse) {
+      pd.partials[(size_t)blockIdx.x * 28 + threadIdx.x] = s;
+    } else {
+      // Hand-over to the last workgroup of the pair WITHOUT a device-scope fence: on this part a release fence writes back the
+      // whole L2 of the XCD (the eight XCDs have private L2s), and 4096 workgroups doing that cost 0.6 ms per launch.  The partial
+      // is stored write-through (agent-scope store, `sc1`), the wave waits for the store to be acknowledged, and only then is the
+      // arrival counted; the consumer reads the partials with agent-scope loads.
+      __hip_atomic_store(pd.partials + (size_t)blockIdx.x * 28 + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+  if (!fuse) return;
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the 28 stores above were issued by this wave (threads 0..27 and thread 0 share wave 0)
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)pd.nblk - 1u;
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) __hip_atomic_store(&st->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+  gn_step_tail(pd, cst);
 }
 
 // ----------------------------------------------------------------------------------------------- LM / GN step
 
-// Eigen::LDLT<6x6>(A).solve(rhs): LDL^T with symmetric diagonal pivoting.  Runs on one lane.
-__device__ void ldlt6_solve(const double* __restrict__ A_in, const double* __restrict__ rhs, double* __restrict__ x) {
-  double A[36];
-  int perm[6];
+// Eigen::LDLT<6x6>(A).solve(rhs): LDL^T with symmetric diagonal pivoting.  Runs on one lane.  Pivoting indexes the matrix
+// dynamically; the work area `ws` (>= 56 doubles, LDS) keeps that out of private memory -- a kernel with a scratch segment pays for it
+// on every wave it launches, and linearize_kernel (which may end in this solve) launches sixteen thousand.
+__device__ void ldlt6_solve(const double* __restrict__ A_in, const double* __restrict__ rhs, double* __restrict__ x, double* __restrict__ ws) {
+  double* A = ws;             // [36]
+  double* y = ws + 36;        // [6]
+  double* col = ws + 42;      // [6]
+  int* perm = reinterpret_cast<int*>(ws + 48);  // [6]
   for (int i = 0; i < 36; ++i) A[i] = A_in[i];
   for (int i = 0; i < 6; ++i) perm[i] = i;
   for (int k = 0; k < 6; ++k) {
@@ -661,7 +685,6 @@ __device__ void ldlt6_solve(const double* __restrict__ A_in, const double* __res
     }
     const double d = A[k * 6 + k];
     if (d == 0.0) continue;
-    double col[6];
     for (int i = k + 1; i < 6; ++i) col[i] = A[i * 6 + k];
     for (int i = k + 1; i < 6; ++i) {
       const double l = col[i] / d;
@@ -671,7 +694,6 @@ __device__ void ldlt6_solve(const double* __restrict__ A_in, const double* __res
     for (int i = k + 1; i < 6; ++i)
       for (int j = i + 1; j < 6; ++j) A[i * 6 + j] = A[j * 6 + i];
   }
-  double y[6];
   for (int i = 0; i < 6; ++i) y[i] = rhs[perm[i]];
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j < i; ++j) y[i] -= A[i * 6 + j] * y[j];
@@ -705,19 +727,24 @@ __device__ void delta_from_d(const double* __restrict__ d, double* __restrict__ 
 }
 
 __device__ void isom_mul(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C) {
-  double t[16];
+  double t[16];  // static indices only (fully unrolled): stays in registers
+#pragma unroll
   for (int r = 0; r < 3; ++r) {
+#pragma unroll
     for (int c = 0; c < 3; ++c) t[r * 4 + c] = A[r * 4 + 0] * B[c] + A[r * 4 + 1] * B[4 + c] + A[r * 4 + 2] * B[8 + c];
     t[r * 4 + 3] = A[r * 4 + 0] * B[3] + A[r * 4 + 1] * B[7] + A[r * 4 + 2] * B[11] + A[r * 4 + 3];
   }
   t[12] = 0; t[13] = 0; t[14] = 0; t[15] = 1;
+#pragma unroll
   for (int i = 0; i < 16; ++i) C[i] = t[i];
 }
 
 // is_converged, LSQ:83-92
 __device__ bool is_converged(const double* __restrict__ delta, double inv_rot_eps, double inv_trans_eps) {
   double rmax = 0.0, tmax = 0.0;
+#pragma unroll
   for (int r = 0; r < 3; ++r) {
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double v = inv_rot_eps * fabs(delta[r * 4 + c] - (r == c ? 1.0 : 0.0));
       rmax = v > rmax ? v : rmax;  // Eigen maxCoeff semantics for finite values
@@ -756,10 +783,9 @@ __device__ double block_error(const PairDesc& pd, const double* __restrict__ T, 
 
 // grid: (pairs), block 1024.  mode 0: full optimiser step (LSQ:67-76 body).  mode 1: only publish H, b, y0 (linearize API).
 // mode 2: only evaluate the error at st->xi with the stored correspondences (compute_error API).
-__global__ __launch_bounds__(1024) void lm_solve_kernel(const PairDesc* __restrict__ descs, ApdConsts cst, int mode) {
-  const PairDesc& pd = descs[blockIdx.x];
+__device__ void lm_solve_body(const PairDesc& pd, const ApdConsts& cst, int mode) {
   PairState* __restrict__ st = pd.state;
-  __shared__ double sH[36], sb[6], sxi[16], sdelta[16], sd[6];
+  __shared__ double sH[36], sb[6], sxi[16], sdelta[16], sd[6], sws[56], sHl[36], snb[6];
   __shared__ double sy0, sred[16];
   __shared__ int sflag;
   if (mode == 2) {
@@ -810,9 +836,8 @@ __global__ __launch_bounds__(1024) void lm_solve_kernel(const PairDesc* __restri
   int ok = 0;
   if (cst.optimizer == 0) {  // step_gn, LSQ:107-123
     if (threadIdx.x == 0) {
-      double nb[6];
-      for (int a = 0; a < 6; ++a) nb[a] = -sb[a];
-      ldlt6_solve(sH, nb, sd);
+      for (int a = 0; a < 6; ++a) snb[a] = -sb[a];
+      ldlt6_solve(sH, snb, sd, sws);
       delta_from_d(sd, sdelta);
       isom_mul(sdelta, st->x0, sxi);
       for (int a = 0; a < 16; ++a) st->x0[a] = sxi[a];
@@ -829,13 +854,12 @@ __global__ __launch_bounds__(1024) void lm_solve_kernel(const PairDesc* __restri
     double nu = 2.0;
     for (int trial = 0; trial < cst.lm_max_iterations; ++trial) {
       if (threadIdx.x == 0) {
-        double Hl[36], nb[6];
-        for (int a = 0; a < 36; ++a) Hl[a] = sH[a];
+        for (int a = 0; a < 36; ++a) sHl[a] = sH[a];
         for (int a = 0; a < 6; ++a) {
-          Hl[a * 6 + a] += lambda;
-          nb[a] = -sb[a];
+          sHl[a * 6 + a] += lambda;
+          snb[a] = -sb[a];
         }
-        ldlt6_solve(Hl, nb, sd);            // LSQ:137-138
+        ldlt6_solve(sHl, snb, sd, sws);     // LSQ:137-138
         delta_from_d(sd, sdelta);           // LSQ:140-142
         isom_mul(sdelta, st->x0, sxi);      // LSQ:144
       }
@@ -893,6 +917,66 @@ __global__ __launch_bounds__(1024) void lm_solve_kernel(const PairDesc* __restri
   }
 }
 
+__global__ __launch_bounds__(1024) void lm_solve_kernel(const PairDesc* __restrict__ descs, ApdConsts cst, int mode) {
+  lm_solve_body(descs[blockIdx.x], cst, mode);
+}
+
+// The Gauss-Newton case of lm_solve_body (mode 0, optimizer 0) for the last workgroup of linearize_kernel: the same sums in the same
+// order, the same step_gn (LSQ:107-123) and bookkeeping (LSQ:67-76), written to need few registers and no private memory (it is
+// inlined into a kernel that launches a wave per 64 source points).
+__device__ void gn_step_tail(const PairDesc& pd, const ApdConsts& cst) {
+  PairState* __restrict__ st = pd.state;
+  __shared__ double tH[36], tb[8], tws[56], td[6], tdelta[16], txi[16];
+  if (threadIdx.x < 28) {
+    double s = 0.0;
+    for (int bk0 = 0; bk0 < pd.nblk; bk0 += 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        v[u] = (bk0 + u < pd.nblk) ? __hip_atomic_load(pd.partials + (size_t)(bk0 + u) * 28 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    const int t = threadIdx.x;
+    if (t < 21) {
+      int r = 0, c = t, rowlen = 6;
+      while (c >= rowlen) {
+        c -= rowlen;
+        ++r;
+        --rowlen;
+      }
+      c += r;
+      tH[r * 6 + c] = s;
+      tH[c * 6 + r] = s;
+    } else {
+      tb[t - 21] = s;  // b[0..5], then the error
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int a = 0; a < 36; ++a) {
+    st->H[a] = tH[a];
+    st->Hfin[a] = tH[a];  // LSQ:120
+  }
+  for (int a = 0; a < 6; ++a) {
+    st->b[a] = tb[a];
+    tb[a] = -tb[a];
+  }
+  st->y0 = tb[6];
+  st->n_linearize += 1;
+  ldlt6_solve(tH, tb, td, tws);      // LSQ:112
+  delta_from_d(td, tdelta);          // LSQ:117-118
+  isom_mul(tdelta, st->x0, txi);     // LSQ:119
+  for (int a = 0; a < 16; ++a) st->x0[a] = txi[a];
+  const int it = st->iter;
+  st->nr_iterations = it;            // LSQ:68
+  const int conv = is_converged(tdelta, 1.0 / cst.rot_eps, 1.0 / cst.trans_eps) ? 1 : 0;  // LSQ:75
+  st->iter = it + 1;
+  st->converged = conv;
+  for (int a = 0; a < 12; ++a) st->Tf[a] = (float)txi[a];  // APD:164 for the next search; LSQ:78 at the end
+  st->done = (conv || it + 1 >= cst.max_iterations) ? 1 : 0;  // read by the NEXT launch only: the kernel boundary orders it
+}
+
 // ----------------------------------------------------------------------------------------------- sharded-source optimiser
 //
 // "One large co-registration" (SURVEY 8e): the source points are split over the ranks of an RCCL communicator, the target (map) is
@@ -913,6 +997,7 @@ __global__ __launch_bounds__(64) void shard_reduce_partials_kernel(const PairDes
 }
 
 __device__ void shard_prepare_trial(PairState* __restrict__ st, double lambda) {
+  __shared__ double ws[56];
   double Hl[36], nb[6];
   for (int a = 0; a < 36; ++a) Hl[a] = st->H[a];
   for (int a = 0; a < 6; ++a) {
@@ -920,7 +1005,7 @@ __device__ void shard_prepare_trial(PairState* __restrict__ st, double lambda) {
     nb[a] = -st->b[a];
   }
   double d[6], delta[16], xi[16];
-  ldlt6_solve(Hl, nb, d);               // LSQ:137-138
+  ldlt6_solve(Hl, nb, d, ws);           // LSQ:137-138
   delta_from_d(d, delta);               // LSQ:140-142
   isom_mul(delta, st->x0, xi);          // LSQ:144
   for (int a = 0; a < 6; ++a) st->sd[a] = d[a];
@@ -975,11 +1060,12 @@ __global__ __launch_bounds__(64) void shard_begin_kernel(const PairDesc* __restr
   st->trial = 0;
   st->trial_active = 0;
   if (cst.optimizer == 0) {  // step_gn, LSQ:107-123
+    __shared__ double ws[56];
     double Hl[36], nb[6], d[6], delta[16], xn[16], x0[16];
     for (int a = 0; a < 36; ++a) Hl[a] = st->H[a];
     for (int a = 0; a < 6; ++a) nb[a] = -st->b[a];
     for (int a = 0; a < 16; ++a) x0[a] = st->x0[a];
-    ldlt6_solve(Hl, nb, d);
+    ldlt6_solve(Hl, nb, d, ws);
     delta_from_d(d, delta);
     isom_mul(delta, x0, xn);
     for (int a = 0; a < 16; ++a) {
