@@ -44,7 +44,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c3"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c5"],
+                    help="c4 (default, the metric's configuration); c3: one 16k scan vs a 100k map; c5: ONE RANK'S SHARE of the 8-GPU configuration -- "
+                         "--pairs scans against one shared --map-points map (map index and covariances are setup, not part of a step)")
+    ap.add_argument("--map-points", type=int, default=1000000)
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--iters", type=int, default=20)
@@ -140,23 +143,44 @@ def main():
         n_pairs, m = args.pairs, n
         for q in range(n_pairs):
             pairs.append(synth.scan_pair(n, m, seed=seed0 + q))
-    else:
+    elif args.workload == "c3":
         n_pairs, m = 1, 100000
         sx, sl = synth.radar_scan(n, seed=seed0)
         tx, tl = synth.local_map(m, seed=seed0 + 1)
         pairs.append((sx, sl, tx, tl, synth.gt_transform()))
+    else:  # c5: every rank holds the SAME map (replicated) and its own scans, taken along the path the map was built on
+        n_pairs, m = args.pairs, args.map_points
+        n_scans = max(6, m // 16384)
+        tx, tl = synth.local_map(m, seed=synth.BASE_SEED + 77, n_scans=n_scans)
+        for q in range(n_pairs):
+            pose = np.eye(4)
+            pose[0, 3] = 0.8 * ((q * 7 + 13 * rank) % n_scans)  # a keyframe position of local_map()
+            sx, sl = synth.radar_scan(n, seed=seed0 + q, sensor_pose=pose)
+            pairs.append((sx, sl, tx, tl, synth.gt_transform() @ pose, pose))  # answer = T_gt pose; the guess is off by T_gt, as in C4
+    guesses = np.stack([np.asarray(pr[5] if len(pr) > 5 else np.eye(4), np.float32) for pr in pairs])
 
     def to_dev(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
+    shared_map = args.workload == "c5"
     resident = []
-    for sx, sl, tx, tl, _ in pairs:
+    for pr in pairs:
+        sx, sl, tx, tl = pr[:4]
         resident.append(dict(
             s=[to_dev(sx[:, 0]), to_dev(sx[:, 1]), to_dev(sx[:, 2]), to_dev(sl)],
-            t=[to_dev(tx[:, 0]), to_dev(tx[:, 1]), to_dev(tx[:, 2]), to_dev(tl)], n=sx.shape[0], m=tx.shape[0]))
+            t=None if shared_map else [to_dev(tx[:, 0]), to_dev(tx[:, 1]), to_dev(tx[:, 2]), to_dev(tl)], n=sx.shape[0], m=tx.shape[0]))
     torch.cuda.synchronize()
     objs = [gorio.ApdGicp(device=local_rank, **params) for _ in range(n_pairs)]
     objs[0].setProfiling(True)
+    map_setup_s = None
+    if shared_map:  # ONE upload, index and k-NN of the map per GPU; every other handle references it (gorio_apd_set_target_shared)
+        t0 = time.perf_counter()
+        objs[0].setInputTarget(pairs[0][2], pairs[0][3])
+        objs[0].calculateCovariances()
+        for o in objs[1:]:
+            o.setInputTargetShared(objs[0])
+        torch.cuda.synchronize()
+        map_setup_s = time.perf_counter() - t0
 
     windows = None
     ugpm_batch = None
@@ -170,8 +194,8 @@ def main():
     ugpm_stage = {}
     ugpm_count = {}
     last = {}
-    ptrs = [([t.data_ptr() for t in r["t"]], r["m"], [t.data_ptr() for t in r["s"]], r["n"]) for r in resident]
-    dev_inputs = gorio.DeviceInputs(objs, sources=[(sp, n_) for (tp, m_, sp, n_) in ptrs], targets=[(tp, m_) for (tp, m_, sp, n_) in ptrs])
+    dev_inputs = gorio.DeviceInputs(objs, sources=[([t.data_ptr() for t in r["s"]], r["n"]) for r in resident],
+                                    targets=None if shared_map else [([t.data_ptr() for t in r["t"]], r["m"]) for r in resident])
     UG = ("lpm", "gram", "corr", "lm", "infer", "ata_lm", "ata_corr")
 
     def set_inputs():
@@ -183,7 +207,7 @@ def main():
 
     def apd_part():
         t1 = time.perf_counter()
-        res = gorio.align_batch(objs)
+        res = gorio.align_batch(objs, guesses)
         phase["align_batch"] += time.perf_counter() - t1
         last["apd"] = res
         return sum(r["n_linearize"] for r in res)
@@ -257,7 +281,7 @@ def main():
             o.set_params(search=0)
         objs[0].setProfiling(True)
         set_inputs()
-        gorio.align_batch(objs)
+        gorio.align_batch(objs, guesses)
         bs, bn = objs[0].getStageTimes()
         brute = bs[1] / max(bn[1], 1)
         for o in objs:
@@ -266,6 +290,8 @@ def main():
     rc = 0
     if rank == 0:
         out = report(args, world, n_pairs, n, m, resident, units, wins, dt, stage_s, stage_n, dict(ugpm_stage), dict(ugpm_count), dict(phase), brute)
+        if map_setup_s is not None:
+            out["map_setup_ms"] = 1e3 * map_setup_s  # upload + search index + k-NN covariances of the shared map, once per GPU
         check = None
         oracle_sample = None
         if not args.no_check:
@@ -389,8 +415,10 @@ def report(args, world, n_pairs, n, m, resident, units, wins, dt, stage_s, stage
         "dtype": "f32 search / f64 accumulate",
         "data": "synthetic",
         "config": {
-            "workload": ("C4: 64 scan pairs 16384x16384 + 64 GP windows 1 s @ 200 Hz per GPU, k-NN covariances + 20 fixed GN iterations per pair"
-                         if wl == "c4" else "C3: 16384-pt scan vs 100000-pt local map, 20 fixed GN iterations"),
+            "workload": {"c4": "C4: 64 scan pairs 16384x16384 + 64 GP windows 1 s @ 200 Hz per GPU, k-NN covariances + 20 fixed GN iterations per pair",
+                         "c3": "C3: 16384-pt scan vs 100000-pt local map, 20 fixed GN iterations",
+                         "c5": f"C5, one rank's share: {n_pairs} scans of {n} points against ONE shared {m}-point map resident on the GPU "
+                               "(source k-NN covariances + 20 fixed GN iterations per scan; map index and covariances are setup)"}[wl],
             "pairs_per_gpu": n_pairs, "source_points": n, "target_points": m, "iterations": args.iters, "optimizer": "GN (convergence test disabled)",
             "search": args.search, "parallelism": f"batch shard x{world} (no collective)"},
         "gp_windows_per_s": (wins / dt) if wins else None,
@@ -472,9 +500,10 @@ def check_against_oracle(args, pairs, windows, timed_T, timed_rec):
     oracle.build()
     p = oa.launch_params(max_iterations=args.iters, optimizer=oa.OPT_GN, rotation_epsilon=0.0, transformation_epsilon=0.0, search=1)
     p.num_threads = usable_cores()
-    sx, sl, tx, tl, _ = pairs[0]
+    sx, sl, tx, tl = pairs[0][:4]
+    guess = np.asarray(pairs[0][5], float) if len(pairs[0]) > 5 else np.eye(4)
     cs, ct = oa.calculate_covariances(sx, p), oa.calculate_covariances(tx, p)
-    ro = oa.align(np.eye(4), sx, sl, tx, tl, cs, ct, p)
+    ro = oa.align(guess, sx, sl, tx, tl, cs, ct, p)
     te, re = _pose_err(ro["T"], timed_T[0])
     out = {"pair0_translation_err_m": te, "pair0_rotation_err_rad": re, "pair0_linearisations": ro["n_linearize"]}
     ok = te < 1e-4 and re < 1e-4 and np.all(np.isfinite(np.asarray(timed_T)))
@@ -504,14 +533,16 @@ def cpu_baseline(sample_pairs, args, windows=None):
     cores = usable_cores()
     p = oa.launch_params(max_iterations=args.iters, optimizer=oa.OPT_GN, rotation_epsilon=0.0, transformation_epsilon=0.0, search=1)
     p.num_threads = cores
+    shared_ct = oa.calculate_covariances(sample_pairs[0][2], p) if args.workload == "c5" else None  # the shared map: setup, as on the GPU
     t0 = time.perf_counter()
     units = 0
     reps = 0
     while time.perf_counter() - t0 < 8.0:  # repeat the sample until ~8 s of CPU work have been spent
-        for sx, sl, tx, tl, _ in sample_pairs:
+        for pr in sample_pairs:
+            sx, sl, tx, tl = pr[:4]
             cs = oa.calculate_covariances(sx, p)
-            ct = oa.calculate_covariances(tx, p)
-            r = oa.align(np.eye(4), sx, sl, tx, tl, cs, ct, p)
+            ct = shared_ct if shared_ct is not None else oa.calculate_covariances(tx, p)
+            r = oa.align(np.asarray(pr[5], float) if len(pr) > 5 else np.eye(4), sx, sl, tx, tl, cs, ct, p)
             units += r["n_linearize"]
         reps += 1
     dt = time.perf_counter() - t0

@@ -411,8 +411,14 @@ __device__ __forceinline__ float lane_f(float v, int lane) { return __uint_as_fl
 #ifdef GORIO_STATS  // development statistics (never in the shipped build): work counters of the pruned searches
 __device__ unsigned long long g_search_stats[8];
 #define STAT_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_search_stats[k], (unsigned long long)(v)); } while (0)
+#define STAT_MAX(k, v) do { if ((threadIdx.x & 63) == 0) atomicMax(&g_search_stats[k], (unsigned long long)(v)); } while (0)
+#define STAT_DECL(name) int name = 0
+#define STAT_INC(name) ++name
 #else
 #define STAT_ADD(k, v) do { } while (0)
+#define STAT_MAX(k, v) do { } while (0)
+#define STAT_DECL(name) do { } while (0)
+#define STAT_INC(name) do { } while (0)
 #endif
 
 // 1-NN of every source point in the target, pruned.  One lane = one source point taken in MORTON order (a wave's 64 queries are
@@ -433,10 +439,6 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   transform_f(st->Tf, si.sx[pq], si.sy[pq], si.sz[pq], qx, qy, qz);
   const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
   const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
-  const scalar_fp tx = as_scalar(ti.sx);
-  const scalar_fp ty = as_scalar(ti.sy);
-  const scalar_fp tz = as_scalar(ti.sz);
-  const scalar_ip to = (scalar_ip)ti.orig;
   const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(ti.tbox);
   // candidates farther than the correspondence gate can never be accepted (APD:183): start from the gate as the bound
   unsigned long long best = ((unsigned long long)__float_as_uint(bound_f) << 32) | 0xffffffffull;
@@ -463,12 +465,11 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);
   const int nsplit = gridDim.y;  // > 1 only when a launch has too few query waves to fill the chip: tile groups are dealt round-robin
   const bool seeded = st->n_linearize > 0;
-  // Seeded launches (every linearisation of an align but the first) use a WORK LIST: with a tight bound a lane needs ~2 tiles but the
-  // 64 lanes of a wave need ~11 different ones, so evaluating every needed tile for all lanes wastes 4/5 of the distance work.
-  // Instead the tiles some lane needs are staged in LDS (up to kNnSlots per batch -- 8: the kernel is latency bound and 17 KB of LDS
-  // per workgroup keeps five waves per SIMD resident, 16 slots cost 30 % -- one float4 per point: x, y, z, original index)
-  // and each lane walks only ITS OWN tiles, reading candidates from its slot -- lanes of one instruction work on different
-  // tiles.  The tests that select the tiles are the same; a tile is selected against the bound the lane had when the tile was
+  // WORK LIST: with a tight bound a lane needs ~2 tiles but the 64 lanes of a wave need ~11 different ones, so evaluating every
+  // needed tile for all lanes would waste 4/5 of the distance work.  Instead the tiles some lane needs are staged in LDS (up to
+  // kNnSlots per batch -- 8: the kernel is latency bound and 17 KB of LDS per workgroup keeps five waves per SIMD resident, 16 slots
+  // cost 30 % -- one float4 per point: x, y, z, original index) and each lane walks only ITS OWN tiles, reading candidates from its
+  // slot -- lanes of one instruction work on different tiles.  A tile is selected against the bound the lane had when the tile was
   // tested (bounds tighten at every batch), a superset of what the final bound would select, so the result is unchanged.
   constexpr int kNnSlots = 8;
   __shared__ float4 s_pts[4][kNnSlots][33];  // 33: slots 528 B apart -> lanes on different slots hit different banks
@@ -477,6 +478,10 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
   const __attribute__((address_space(1))) float* gy = (const __attribute__((address_space(1))) float*)ti.sy;
   const __attribute__((address_space(1))) float* gz = (const __attribute__((address_space(1))) float*)ti.sz;
   const __attribute__((address_space(1))) int* go = (const __attribute__((address_space(1))) int*)ti.orig;
+  // The first, unseeded launch of an align has only the gate as its bound.  It runs the same work list, but flushes its first
+  // batch after two tiles so that every lane owns a real bound before the remaining tiles are tested.
+  int flush_at = seeded ? kNnSlots : 2;
+  STAT_DECL(wave_rounds);
   unsigned int mneed = 0u;  // slots of the current batch this lane must visit
   int slot_tile = 0;        // lane s: tile held by slot s
   int nslots = 0;           // wave-uniform
@@ -495,6 +500,7 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
     STAT_ADD(3, __builtin_popcount(mneed));  // lane 0's own item count (a sample of the per-lane mean)
     while (__ballot(mneed != 0u)) {
       STAT_ADD(4, 1);
+      STAT_INC(wave_rounds);
       if (mneed != 0u) {
         const int sl = __builtin_ctz(mneed);
         mneed &= mneed - 1u;
@@ -512,49 +518,93 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
     nslots = 0;
     __builtin_amdgcn_wave_barrier();
   };
-  for (int v = 0; v < 2 * ng; ++v) {
-    const int off = (v + 1) >> 1;
-    const int g = (v & 1) ? g0 - off : g0 + off;
-    if (g < 0 || g >= ng) continue;
-    if (nsplit > 1 && (g % nsplit) != (int)blockIdx.y) continue;
-    const int tl = g * 64 + lane;
-    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
-    if (tl < ti.n_tiles) {
-      lo = tb4[2 * (size_t)tl];
-      hi = tb4[2 * (size_t)tl + 1];
-    }
-    const float wb = wave_max(bestd);
-    unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= wb);
-    STAT_ADD(7, __builtin_popcountll(mask));
-    while (mask) {
-      const int tlane = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
-      const bool need = box_bound(qx, qy, qz, bx) <= bestd;
-      if (__ballot(need) == 0) continue;
-      STAT_ADD(6, 1);
-      if (seeded) {
-        if (need) mneed |= 1u << nslots;
-        if (lane == nslots) slot_tile = g * 64 + tlane;
-        if (++nslots == kNnSlots) flush();
-        continue;
-      }
-      const int j0 = (g * 64 + tlane) * 32;
+  // THREE levels.  A 1 M-point map has 31 250 tiles in 489 groups of 64; testing every group's tile boxes costs a wave 29 k
+  // instructions before it has looked at a single point.  So the super-tile boxes (16 tiles = 512 points, four per group) are tested
+  // first, 64 per instruction (one per lane) against the box of the wave's queries and its loosest bound: a bit mask of the groups
+  // that can matter at all.  Only those groups get the tile-level test, nearest group (in index order, which follows space) first.
+  constexpr int kGroupWords = 32;  // mask words per pass: 2048 groups = 4.2 M target points; larger targets take several passes
+  __shared__ unsigned long long s_gmask[4][kGroupWords];
+  const float4* __restrict__ sb4 = reinterpret_cast<const float4*>(ti.sbox);
+  for (int c0 = 0; c0 < ng; c0 += kGroupWords * 64) {
+    const int cg = ng - c0 < kGroupWords * 64 ? ng - c0 : kGroupWords * 64;
+    const int nwords = (cg + 63) >> 6;
+    const float wb0 = wave_max(bestd);
+    for (int w = 0; w < nwords; ++w) {
+      unsigned long long word = 0ull;
 #pragma unroll
-      for (int gg = 0; gg < 32; gg += 8) {
-        float d[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) d[u] = sqdist3(qx, qy, qz, tx[j0 + gg + u], ty[j0 + gg + u], tz[j0 + gg + u]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const unsigned long long key = ((unsigned long long)__float_as_uint(d[u]) << 32) | (unsigned int)to[j0 + gg + u];
-          best = key < best ? key : best;
+      for (int q4 = 0; q4 < 4; ++q4) {  // one ballot = 64 super tiles = 16 groups
+        const int gbase = c0 + w * 64 + q4 * 16;
+        if (gbase < ng) {
+          const int sl = gbase * 4 + lane;
+          bool pass = false;
+          if (sl < ti.n_super) pass = box_box_bound(qlo, qhi, sb4[2 * (size_t)sl], sb4[2 * (size_t)sl + 1]) <= wb0;
+          unsigned long long m = __ballot(pass);
+          m |= m >> 1;
+          m |= m >> 2;  // bit 4 j: any of the four super tiles of group j
+          m &= 0x1111111111111111ull;
+          m = (m | (m >> 3)) & 0x0303030303030303ull;
+          m = (m | (m >> 6)) & 0x000f000f000f000full;
+          m = (m | (m >> 12)) & 0x000000ff000000ffull;
+          m = (m | (m >> 24)) & 0xffffull;
+          word |= m << (q4 * 16);
         }
       }
-      bestd = __uint_as_float((unsigned int)(best >> 32));
+      if (lane == 0) s_gmask[wave][w] = word;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int gl = g0 - c0;  // where near neighbours are expected, relative to this pass
+    gl = gl < 0 ? 0 : (gl >= cg ? cg - 1 : gl);
+    const int w0 = gl >> 6;
+    for (int v = 0; v < 2 * nwords; ++v) {
+      const int woff = (v + 1) >> 1;
+      const int w = (v & 1) ? w0 - woff : w0 + woff;
+      if (w < 0 || w >= nwords) continue;
+      const unsigned long long mw = s_gmask[wave][w];
+      unsigned long long gm = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(mw >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned int)mw);
+      const int pivot = w == w0 ? (gl & 63) : (w > w0 ? 0 : 63);
+      while (gm) {
+        // the set bit nearest to the pivot: groups are visited outward from where the queries sit, so the bound tightens early
+        const unsigned long long up = gm & (~0ull << pivot), dn = gm & ~(~0ull << pivot);
+        const int bu = up ? __builtin_ctzll(up) : 1000, bd = dn ? 63 - __builtin_clzll(dn) : -1000;
+        const int bit = (bu - pivot) <= (pivot - bd) ? bu : bd;
+        gm &= ~(1ull << bit);
+        const int g = c0 + w * 64 + bit;
+        if (nsplit > 1 && (g % nsplit) != (int)blockIdx.y) continue;
+        const int tl = g * 64 + lane;
+        float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+        if (tl < ti.n_tiles) {
+          lo = tb4[2 * (size_t)tl];
+          hi = tb4[2 * (size_t)tl + 1];
+        }
+        const float wb = wave_max(bestd);
+        unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= wb);
+        STAT_ADD(7, __builtin_popcountll(mask));
+        while (mask) {
+          const int tlane = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+          const bool need = box_bound(qx, qy, qz, bx) <= bestd;
+          if (__ballot(need) == 0) continue;
+          STAT_ADD(6, 1);
+          if (need) mneed |= 1u << nslots;
+          if (lane == nslots) slot_tile = g * 64 + tlane;
+          if (++nslots >= flush_at) {
+            flush();
+            flush_at = kNnSlots;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the mask words are rewritten by the next pass
   }
   if (nslots > 0) flush();
+#ifdef GORIO_STATS
+  STAT_MAX(2, wave_rounds);
+  STAT_ADD(1, wave_rounds > 64 ? 1 : 0);
+  STAT_ADD(0, wave_rounds > 64 ? wave_rounds : 0);
+#endif
   if (p < si.n && (unsigned int)best != 0xffffffffu) {
     if (nsplit > 1) atomicMin(pd.best_key + si.orig[p], best);
     else pd.best_key[si.orig[p]] = best;
