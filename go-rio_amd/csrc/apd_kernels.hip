@@ -372,7 +372,6 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(const KnnJob* __restr
   const int n = job.cloud.n;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int k = job.k;
   float bd[K];
   int bi[K];
 #pragma unroll

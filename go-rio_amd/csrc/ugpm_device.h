@@ -9,7 +9,7 @@
 namespace gorio {
 
 constexpr int kAtaKSplit = 1;       // workgroups sharing the rows of J for one group of output tiles
-constexpr int kAtaTilesLm = 32, kAtaTilesCorr = 48;  // 16 x 16 output tiles per workgroup (8 waves x 4 / 6 accumulators)
+constexpr int kAtaTilesLm = 24, kAtaTilesCorr = 48;  // 16 x 16 output tiles per workgroup (8 waves x 4 / 6 accumulators)
 constexpr int kAtaMaxGroups = 28;
 constexpr int kWinInts = 48;        // ints per window: lmi[16], status at 16, ata_cnt at 20
 

@@ -1745,13 +1745,11 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
 // C = A^T A (and g = A^T r) for A (m x n, row-major) on the fp64 matrix cores.
 // v_mfma_f64_16x16x4_f64 takes A^T as its 16 x 4 operand and A as its 4 x 16 operand; BOTH are row segments of A (lane l supplies
 // A[k0 + (l >> 4)][c0 + (l & 15)]), so no transpose is ever formed.  Result layout: col = lane & 15, row = (lane >> 4) + 4 reg.
-// Work split: the lower-triangular 16 x 16 tiling of C is cut into groups of <= 96 tiles (12 accumulators per wave, 8 waves) and
-// the rows of A into kAtaKSplit slices; one workgroup owns (slice, group).  It streams its rows through LDS in chunks of 16 (8
-// for n > 496) -- every element of A is read from L2 once per group instead of once per output tile -- and writes its partial
-// tiles in accumulator order (fully coalesced).  The LAST of the kAtaKSplit workgroups of a group to finish (arrival counter) adds
-// the partials in slice order, so the result does not depend on the order of arrival, and writes C symmetrically.
-// grid: 1-D, ceil(units * kAtaKSplit / 8) * 8 workgroups with unit = (window, group): the kAtaKSplit workgroups of a unit are 8
-// apart in launch order, i.e. on the same XCD (workgroups are dealt to XCDs round-robin), so their partials meet in one L2.
+// Work split: the lower-triangular 16 x 16 tiling of C is cut into groups of TPG tiles (TPG / 8 accumulators per wave, 8 waves); one
+// workgroup owns a group over ALL rows of A.  It streams the rows through LDS in chunks of 16 (8 for n > 496) -- every element of
+// A is read from L2 once per group instead of once per output tile -- and writes C symmetrically.  (Splitting the rows over several
+// workgroups with partial tiles, an arrival counter and an ordered reduction was measured in round 1 and dropped.)
+// grid: 1-D, ceil(units / 8) * 8 workgroups with unit = (window, group).
 // which: 0 rot problem, 1 vel problem, 2 correlation.  Dynamic LDS: 2 * KC * (npad + 1) doubles.  n <= 512 when g is formed.
 __device__ __forceinline__ int ata_npad(int n) { return ((n + 15) / 32) * 32 + 16; }  // >= round_up(n, 16); rows 32 banks apart
 
@@ -1813,6 +1811,14 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
   double gacc = 0.0;
+  // g = A^T r rides along.  One thread per column in one workgroup made a 16-step dependent LDS chain per chunk the longest phase
+  // of that workgroup (a quarter of its time); instead every group owns a slice of the columns and all 512 threads share it: thread
+  // (gpart, column) takes every gparts-th row of a chunk, the partial sums meet in LDS at the end in a fixed order.
+  const int gj0 = (int)((long)grp * n / ng), gj1 = (int)((long)(grp + 1) * n / ng);
+  const int gcolw = ((gj1 - gj0 + 63) / 64) * 64;
+  const int gparts = gcolw <= 64 ? 8 : (gcolw <= 128 ? 4 : (gcolw <= 256 ? 2 : 1));
+  const int gpart = (int)threadIdx.x / gcolw, gj = gj0 + (int)threadIdx.x % gcolw;
+  const bool gcol = g != nullptr && gpart < gparts && gj < gj1;
   // chunk loader: wave v brings rows v, v + 8 (KC = 16) of the chunk, 64 columns per instruction
   constexpr int RMAX = KC / 8;
   double pre[RMAX][CMAX];
@@ -1866,9 +1872,8 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc[t], 0, 0, 0);
     }
     CHOL_T(1);
-    if (g != nullptr && grp == 0 && tid < n) {
-#pragma unroll
-      for (int kk = 0; kk < KC; ++kk) gacc += src[kk * npad + tid] * rl[buf * KC + kk];
+    if (gcol) {  // this thread's share of g = A^T r: column gj, rows gpart, gpart + gparts, ... of the chunk
+      for (int kk = gpart; kk < KC; kk += gparts) gacc += src[kk * npad + gj] * rl[buf * KC + kk];
     }
     CHOL_T(2);
     if (ck + 1 < c_hi) stash(buf ^ 1);
@@ -1876,7 +1881,8 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
     __syncthreads();
     CHOL_T(4);
   }
-  if constexpr (kAtaKSplit == 1) {  // this workgroup saw every row: its accumulators ARE the result
+  static_assert(kAtaKSplit == 1, "a split of the rows over workgroups (partial tiles + ordered reduction) was measured and dropped");
+  {  // this workgroup saw every row: its accumulators ARE the result
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (t < nt) {
@@ -1890,55 +1896,17 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
         }
       }
     }
-    if (g != nullptr && grp == 0 && tid < n) g[tid] = gacc;
-    return;
-  }
-  // partial results, accumulator order: [(ks * ntile + q) * 256 + reg * 64 + lane]
-  double* part = w.ata_part;
-  double* gpart = part + (size_t)kAtaKSplit * ntile * 256;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t < nt) {
-      double* dst = part + ((size_t)ks * ntile + qv[t]) * 256 + lane;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) dst[rg * 64] = acc[t][rg];
-    }
-  }
-  if (g != nullptr && grp == 0 && tid < n) gpart[(size_t)ks * n + tid] = gacc;
-  CHOL_T(5);
-  __threadfence();
-  __syncthreads();
-  CHOL_T(6);
-  if (tid == 0) {
-    const int prev = atomicAdd(w.ata_cnt + grp, 1);
-    s_last = prev == kAtaKSplit - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t < nt) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
+    if (g != nullptr) {  // uniform per workgroup.  The staged chunks are dead: their LDS holds the partial sums [gparts][gcolw]
+      __syncthreads();
+      if (gpart < gparts) ata_lds[gpart * gcolw + (int)threadIdx.x % gcolw] = gcol ? gacc : 0.0;
+      __syncthreads();
+      if (tid < gj1 - gj0) {
         double v = 0.0;
-#pragma unroll
-        for (int s2 = 0; s2 < kAtaKSplit; ++s2) v += part[((size_t)s2 * ntile + qv[t]) * 256 + rg * 64 + lane];
-        const int i = trofs[t] + lk + 4 * rg, j = tcofs[t] + lr;
-        if (i < n && j < n) {
-          C[(size_t)i * n + j] = v;
-          C[(size_t)j * n + i] = v;
-        }
+        for (int q = 0; q < gparts; ++q) v += ata_lds[q * gcolw + tid];
+        g[gj0 + tid] = v;
       }
     }
   }
-  if (g != nullptr && grp == 0 && tid < n) {
-    double v = 0.0;
-#pragma unroll
-    for (int s2 = 0; s2 < kAtaKSplit; ++s2) v += gpart[(size_t)s2 * n + tid];
-    g[tid] = v;
-  }
-  if (tid == 0) w.ata_cnt[grp] = 0;
   CHOL_T(7);
 }
 
