@@ -388,7 +388,7 @@ def report(args, world, n_pairs, n, m, resident, units, wins, dt, stage_s, stage
         "lm_solve_kernel": (stage_s[3], stage_n[3]),
     }
     if ugpm_stage:
-        cand["ata_kernel<4, 16, 32>"] = (ugpm_stage.get("ata_lm", 0.0), ugpm_count.get("ata_lm", 0))
+        cand["ata_kernel<4, 16, 24>"] = (ugpm_stage.get("ata_lm", 0.0), ugpm_count.get("ata_lm", 0))
         cand["ata_kernel<8, 16, 48>"] = (ugpm_stage.get("ata_corr", 0.0), ugpm_count.get("ata_corr", 0))
     dom = max(cand, key=lambda k: cand[k][0])
     dom_avg = avg(*cand[dom])

@@ -1789,7 +1789,6 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
   const int c_lo = ks * nck / kAtaKSplit, c_hi = (ks + 1) * nck / kAtaKSplit;
   extern __shared__ double ata_lds[];  // [2][KC][npad] staged rows of A, then [2][KC] staged entries of r
   double* rl = ata_lds + (size_t)2 * KC * npad;
-  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
   constexpr int NT = TPG / 8;
