@@ -619,7 +619,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
           if (!r.active) continue;
           any = true;
           const UgpmWin* dw_ = c.d_wins + r.g0;
-          ug::lm_step_kernel<<<r.nw, 512, 0, r.s>>>(dw_);
+          ug::lm_step_kernel<<<dim3(r.nw, problem == 1 ? kVelBlocks : 1), 512, 0, r.s>>>(dw_);
           if (problem == 0) ug::rot_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 0);
           else ug::vel_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 0);
           if (problem == 0) {

@@ -1397,13 +1397,33 @@ __device__ __forceinline__ void wave_row_dots3(const double* __restrict__ a, siz
   for (int q = 0; q < 3; ++q) out[q] = t[q];
 }
 
+// lm_step_kernel may run as several workgroups per window, all of which read the solver's control words; what the step consumes
+// ("a fresh linearisation arrived", "first evaluation") and counts (iterations) is therefore written here, by ONE thread of the
+// candidate evaluation that follows every step in stream order -- nothing in between reads these words.
+__device__ __forceinline__ void lm_step_bookkeeping(const UgpmWin& w) {
+  w.lmi[3] = 0;
+  w.lmi[8] = 0;
+  w.lmi[0] += 1;
+}
+
 // Acceptance test of a trust-region step (Ceres 2.1 TrustRegionMinimizer: tolerances of preint.h:943-948, rho > 1e-3, radius
 // update), evaluated from the candidate residuals res_new.  It is fused into the kernels that re-linearise after the step, whose
 // grid has several workgroups per window: EVERY workgroup evaluates the (deterministic) decision for itself from inputs none of
-// them writes (res_new, lmc[0], lmc[4..6], lmi[4]), and only the workgroup with commit == true stores the new solver state.
+// them writes (res_new, lmc[0], lmc[4], lmc[8..13], lmi[9..11]), and only the workgroup with commit == true stores the new solver state.
 // Returns 1 accepted, 0 rejected / invalid step, -1 terminated.  All threads of the workgroup must call it.
 __device__ int lm_decide_block(const UgpmWin& w, int m, int n, bool commit, double* sred /* [8] LDS */) {
-  if (!w.lmi[4]) {  // StepIsInvalid
+  // the step came from lm_step_kernel in one piece (problem #1) or as kVelBlocks independent diagonal blocks (problem #2)
+  const int nblk = w.lmi[7] == 1 ? kVelBlocks : 1;
+  bool step_ok = true;
+  double mcc = 0.0, sn2 = 0.0;
+  for (int q = 0; q < nblk; ++q) {
+    step_ok = step_ok && w.lmi[9 + q] != 0;
+    mcc += w.lmc[8 + q];
+    sn2 += w.lmc[11 + q];
+  }
+  if (!(mcc > 0.0)) step_ok = false;
+  const double sn = sqrt(sn2);
+  if (!step_ok) {  // StepIsInvalid
     if (commit && threadIdx.x == 0) {
       w.lmc[2] = w.lmc[2] / w.lmc[3];
       w.lmc[3] *= 2.0;
@@ -1418,10 +1438,10 @@ __device__ int lm_decide_block(const UgpmWin& w, int m, int n, bool commit, doub
   const double cost_change = cost - cost_new;
   int verdict;
   double rho = 0.0;
-  if (w.lmc[6] <= 1e-8 * (w.lmc[4] + 1e-8)) verdict = -2;              // parameter_tolerance
+  if (sn <= 1e-8 * (w.lmc[4] + 1e-8)) verdict = -2;                     // parameter_tolerance
   else if (fabs(cost_change) <= 1e-10 * cost) verdict = -1;             // function_tolerance, preint.h:948
   else {
-    rho = cost_change / w.lmc[5];
+    rho = cost_change / mcc;
     verdict = rho > 1e-3 ? 1 : 0;                                       // min_relative_decrease
   }
   __syncthreads();  // every thread has read the solver state before the committing workgroup's thread 0 rewrites it
@@ -1472,6 +1492,7 @@ __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict
   if (*w.status != 0 || w.lmi[1]) return;
   const int S = w.S, G = w.G, n = 3 * S;
   __shared__ double sred[8];
+  if (mode == 0 && blockIdx.y == 0 && threadIdx.x == 0) lm_step_bookkeeping(w);
   if (mode == 1) {  // step acceptance (see lm_decide_block), then the Jacobian only after an accepted step -- at x_new, which is
                     // what the committing workgroup is copying into x meanwhile
     if (lm_decide_block(w, 3 * S + 3 * G, n, blockIdx.y == 0, sred) != 1) return;
@@ -1555,6 +1576,7 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
   const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || w.lmi[1]) return;
   if (mode == 1 && !w.lmi[3]) return;
+  if (mode == 0 && blockIdx.y == 0 && threadIdx.x == 0) lm_step_bookkeeping(w);
   const int S = w.S, V = w.V, n = 3 * S;
   const double* x = mode == 0 ? w.lmv + 6 * (size_t)n : w.lmv + 5 * (size_t)n;
   double* res = mode == 0 ? w.res_new : w.res;
@@ -1966,13 +1988,22 @@ __global__ __launch_bounds__(256) void lm_begin_kernel(const UgpmWin* __restrict
 }
 
 // One trust-region step: (on fresh J^T J) cost / gradient test / Jacobi scaling, then solve (D J^T J D + diag / radius) y = D g,
-// step = -y, delta = D step, model cost change, candidate x_new.  grid: (windows), block 256.
+// step = -y, delta = D step, model cost change, candidate x_new.  grid: (windows, blocks), block 512.
+// blocks = 1: the whole 3S x 3S system (problem #1).  blocks = kVelBlocks (problem #2): VelCost's Jacobian is R(t)^T applied to
+// per-channel rows (cost_functions.h:375) and R R^T = I, the GpNorm blocks are per channel, so J^T J is block diagonal with one
+// S x S block per velocity channel (its off-diagonal blocks are rounding noise, 1e-16 of the diagonal ones): workgroup b factors
+// and solves block b alone -- a 66 x 66 factorisation instead of 198 x 198 on the critical path of every velocity iteration.
+// Every workgroup evaluates the (cheap, deterministic) global quantities for itself -- cost, gradient maximum, |x| -- and writes
+// identical values; the words a step consumes or counts are updated by the evaluation kernel that follows (lm_step_bookkeeping), so no
+// workgroup reads a control word another one writes in the same launch.
 __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || w.lmi[1]) return;
   const int n = 3 * w.S;
   const int problem = w.lmi[7];
   const int m = problem == 0 ? 3 * w.S + 3 * w.G : 3 * w.V + 3 * w.S;
+  const int nblk = (int)gridDim.y, blk = (int)blockIdx.y;
+  const int j0 = (int)((long)n * blk / nblk), j1 = (int)((long)n * (blk + 1) / nblk), ns = j1 - j0;  // this workgroup's unknowns
   double* g = w.lmv;
   double* scale = w.lmv + (size_t)n;
   double* diag = w.lmv + 2 * (size_t)n;
@@ -1995,21 +2026,18 @@ __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict_
     gm = block_max(gm, sred);
     xn2 = block_sum(xn2, sred);
     if (w.lmi[8])
-      for (int j = threadIdx.x; j < n; j += blockDim.x) scale[j] = 1.0 / (1.0 + sqrt(w.JtJ[(size_t)j * n + j]));  // Jacobi scaling, fixed
+      for (int j = j0 + (int)threadIdx.x; j < j1; j += blockDim.x) scale[j] = 1.0 / (1.0 + sqrt(w.JtJ[(size_t)j * n + j]));  // Jacobi scaling, fixed
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {  // the same values from every workgroup of the window
       w.lmc[0] = c;
       w.lmc[4] = sqrt(xn2);
       if (w.lmi[8]) w.lmc[7] = c;
-      w.lmi[8] = 0;
-      w.lmi[3] = 0;
       if (gm <= 1e-10) {  // gradient_tolerance
         w.lmi[1] = 1;
         w.lmi[5] = 3;
       }
     }
-    __syncthreads();
-    if (w.lmi[1]) return;
+    if (gm <= 1e-10) return;
   }
   if (w.lmi[0] >= 50) {  // max_num_iterations, preint.h:945
     if (threadIdx.x == 0) { w.lmi[1] = 1; w.lmi[5] = 4; }
@@ -2020,45 +2048,44 @@ __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict_
     if (threadIdx.x == 0) { w.lmi[1] = 1; w.lmi[5] = 5; }
     return;
   }
-  if (threadIdx.x == 0) w.lmi[0] += 1;
   if (!w.lmi[2])
-    for (int j = threadIdx.x; j < n; j += blockDim.x) diag[j] = fmin(fmax(w.JtJ[(size_t)j * n + j] * scale[j] * scale[j], 1e-6), 1e32);
+    for (int j = j0 + (int)threadIdx.x; j < j1; j += blockDim.x) diag[j] = fmin(fmax(w.JtJ[(size_t)j * n + j] * scale[j] * scale[j], 1e-6), 1e32);
   __syncthreads();
-  double* L = w.lhs;
+  double* L = w.lhs + (size_t)j0 * n + j0;  // this workgroup's diagonal block inside the n x n buffer (row stride n)
   __shared__ double xs[kCholMaxN / 2];
-  const bool fused = n < 384 && n <= (int)blockDim.x && n <= kCholMaxN / 2;  // rhs rides through the factorisation, blocked back-substitution
-  for (int i = threadIdx.x >> 6; i < n; i += (int)(blockDim.x >> 6)) {  // lower triangle of D J^T J D + diag / radius, one row per wave
-    const double si = scale[i];
+  const bool fused = ns < 384 && ns <= (int)blockDim.x && ns <= kCholMaxN / 2;  // rhs rides through the factorisation, blocked back-substitution
+  for (int i = threadIdx.x >> 6; i < ns; i += (int)(blockDim.x >> 6)) {  // lower triangle of D J^T J D + diag / radius, one row per wave
+    const double si = scale[j0 + i];
     for (int j = threadIdx.x & 63; j <= i; j += 64)
-      L[(size_t)i * n + j] = w.JtJ[(size_t)i * n + j] * si * scale[j] + (i == j ? diag[i] / radius : 0.0);
+      L[(size_t)i * n + j] = w.JtJ[(size_t)(j0 + i) * n + j0 + j] * si * scale[j0 + j] + (i == j ? diag[j0 + i] / radius : 0.0);
   }
-  double* rhs = w.lmv + 7 * (size_t)n;  // right-hand side row carried through the factorisation (global, like the matrix)
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    step[j] = g[j] * scale[j];
-    if (fused) rhs[j] = g[j] * scale[j];
+  double* rhs = w.lmv + 7 * (size_t)n + j0;  // right-hand side row carried through the factorisation (global, like the matrix)
+  for (int j = threadIdx.x; j < ns; j += blockDim.x) {
+    step[j0 + j] = g[j0 + j] * scale[j0 + j];
+    if (fused) rhs[j] = g[j0 + j] * scale[j0 + j];
   }
   __syncthreads();
-  bool valid = block_cholesky(L, n, n, chol, &sflag, fused ? rhs : nullptr);
+  bool valid = block_cholesky(L, ns, n, chol, &sflag, fused ? rhs : nullptr);
   if (valid) {
     if (fused) {
-      for (int j = threadIdx.x; j < n; j += blockDim.x) xs[j] = rhs[j];
+      for (int j = threadIdx.x; j < ns; j += blockDim.x) xs[j] = rhs[j];
       __syncthreads();
-      block_backward(L, n, n, xs, chol);
-      for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = xs[j];
+      block_backward(L, ns, n, xs, chol);
+      for (int j = threadIdx.x; j < ns; j += blockDim.x) step[j0 + j] = xs[j];
     } else {
       double* xp = &chol.P[0][0];  // the panel buffer is free again: solve in LDS
-      for (int j = threadIdx.x; j < n; j += blockDim.x) xp[j] = step[j];
+      for (int j = threadIdx.x; j < ns; j += blockDim.x) xp[j] = step[j0 + j];
       __syncthreads();
       if (threadIdx.x < 64) {
-        wave_forward<1>(L, n, n, xp, 1, 0);
-        wave_backward(L, n, n, xp);
+        wave_forward<1>(L, ns, n, xp, 1, 0);
+        wave_backward(L, ns, n, xp);
       }
       __syncthreads();
-      for (int j = threadIdx.x; j < n; j += blockDim.x) step[j] = xp[j];
+      for (int j = threadIdx.x; j < ns; j += blockDim.x) step[j0 + j] = xp[j];
     }
     __syncthreads();
     double bad = 0.0;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    for (int j = j0 + (int)threadIdx.x; j < j1; j += blockDim.x) {
       step[j] = -step[j];
       if (!isfinite(step[j])) bad = 1.0;
       delta[j] = step[j] * scale[j];
@@ -2066,26 +2093,25 @@ __global__ __launch_bounds__(512) void lm_step_kernel(const UgpmWin* __restrict_
     bad = block_max(bad, sred);
     valid = bad == 0.0;
   }
-  double mcc = 0.0, sn = 0.0;
-  if (valid) {  // model cost change -(J d)^T (r + J d / 2) = -(d.g + d^T (J^T J) d / 2)
+  double mcc = 0.0, sn2 = 0.0;
+  if (valid) {  // this block's share of the model cost change -(J d)^T (r + J d / 2) = -(d.g + d^T (J^T J) d / 2)
     double acc = 0.0;
-    for (int i = threadIdx.x >> 6; i < n; i += (int)(blockDim.x >> 6)) {  // 0.5 d^T (J^T J) d, one matrix row per wave (coalesced)
+    for (int i = j0 + (int)(threadIdx.x >> 6); i < j1; i += (int)(blockDim.x >> 6)) {  // 0.5 d^T (J^T J) d, one matrix row per wave (coalesced)
       const double hi = 0.5 * delta[i];
-      for (int j = threadIdx.x & 63; j < n; j += 64) acc += hi * w.JtJ[(size_t)i * n + j] * delta[j];
+      for (int j = j0 + (int)(threadIdx.x & 63); j < j1; j += 64) acc += hi * w.JtJ[(size_t)i * n + j] * delta[j];
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = j0 + (int)threadIdx.x; i < j1; i += blockDim.x) {
       acc += delta[i] * g[i];
-      sn += delta[i] * delta[i];
+      sn2 += delta[i] * delta[i];
       xn[i] = x[i] + delta[i];
     }
     mcc = -block_sum(acc, sred);
-    sn = sqrt(block_sum(sn, sred));
-    if (!(mcc > 0.0)) valid = false;
+    sn2 = block_sum(sn2, sred);
   }
-  if (threadIdx.x == 0) {
-    w.lmi[4] = valid ? 1 : 0;
-    w.lmc[5] = mcc;
-    w.lmc[6] = sn;
+  if (threadIdx.x == 0) {  // lm_decide_block adds the blocks up (the step is invalid unless every block is valid and the sum positive)
+    w.lmi[9 + blk] = valid ? 1 : 0;
+    w.lmc[8 + blk] = mcc;
+    w.lmc[11 + blk] = sn2;
   }
 }
 
