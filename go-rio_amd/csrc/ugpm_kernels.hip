@@ -1188,7 +1188,7 @@ __device__ __forceinline__ void small_gemm_nn(const double* __restrict__ A, cons
 
 // grid: (6 channels, windows), block 256.  preint.h:832-866 for one channel: K + sz2 I = L L^T (block_cholesky), L^-1 by the
 // blocked 16-column forward substitution, K^-1 = L^-T L^-1, K K^-1 and K_int K^-1 on the matrix cores.
-__global__ __launch_bounds__(256) void gram_kernel(const UgpmWin* __restrict__ wins) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0) return;
   const int c = blockIdx.x, S = w.S;
@@ -2148,7 +2148,7 @@ __global__ __launch_bounds__(512) void corr_factor_kernel(const UgpmWin* __restr
 
 // diag(A^-1) = squared column norms of L^-1, 16 columns per workgroup; then dsc = state_std / sqrt(diag(A^-1)) (preint.h:1487-1489).
 // grid: (ceil(6S / 16), windows), block 256.  Dynamic LDS: (rows + 16) * 17 doubles for X, rows = 6 max_S.
-__global__ __launch_bounds__(256) void corr_diag_kernel(const UgpmWin* __restrict__ wins) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void corr_diag_kernel(const UgpmWin* __restrict__ wins) {
   const UgpmWin w = load_win(wins, blockIdx.y);
   if (*w.status != 0 || !w.correlate) return;
   const int n = 6 * w.S;
