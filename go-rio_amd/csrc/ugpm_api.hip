@@ -33,7 +33,7 @@ struct Ctx {  // per-thread, per-device cached buffers
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // the state-correlation chain runs here, beside the two GP fits (a helper thread in the reference, preint.h:939-1064)
   hipEvent_t ev_jac = nullptr, ev_corr = nullptr, ev_up = nullptr;
-  struct Group { hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev_jac = nullptr, ev_corr = nullptr, ev_done = nullptr; };
+  struct Group { hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev_jac = nullptr, ev_corr = nullptr, ev_done = nullptr, ev_tab = nullptr; };
   std::vector<Group> groups;  // group 0 = (stream, stream2)
   double* ws = nullptr;
   size_t ws_cap = 0;
@@ -111,12 +111,9 @@ size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* b
   u.Kinv = take(6 * S * S); u.KKinv = take(6 * S * S); u.KintKinv = take(3 * S * S); u.var = take(6 * S); u.wgp = take(6 * S); u.sstd = take(6 * S);
   u.KsKinv = take(3 * G * S); u.KsIntKinv = take(3 * G * S); u.KgyrIntKinv = take(3 * V * S); u.KvelKinv = take(3 * V * S);
   u.Jrot = take(mrot * n); u.Jvel = take(mvel * n); u.res = take(std::max(mrot, mvel)); u.res_new = take(std::max(mrot, mvel));
-  u.JtJ = take(n * n); u.lhs = take(n * n); u.lmv = take(8 * n); u.sample_tmp = take(std::max(G, V) * 24);
+  u.JtJ = take(n * n); u.lhs = take(n * n); u.lmv = take(8 * n); u.sample_tmp = take(std::max(G, V) * 24); u.sample_tmp_c = take(std::max(G, V) * 24);
   if (w.correlate) { u.Jc = take(mc * nc); u.Ac = take(nc * nc); }
-  {
-    const size_t nmax = w.correlate ? nc : n, tmax = (nmax + 15) / 16, tiles = tmax * (tmax + 1) / 2;
-    u.ata_part = take(kAtaKSplit * (tiles * 256 + nmax));
-  }
+  u.ata_part = nullptr;  // (split-K partial tiles: dropped)
   u.dsc = take(nc);
   u.alpha = take(6 * S); u.state_r = take(3 * S); u.d_state_bw = take(3 * S * 3); u.d_d_r_dt = take(3 * S); u.d_vel_bv = take(3 * S * 3); u.d_vel_bw = take(3 * S * 3);
   u.d_vel_dt = take(3 * S); u.out = outp; u.lmc = take(16);
@@ -241,7 +238,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       hipStreamDestroy(c.groups[g].s); hipStreamDestroy(c.groups[g].s2);
       hipEventDestroy(c.groups[g].ev_jac); hipEventDestroy(c.groups[g].ev_corr);
     }
-    for (auto& g : c.groups) hipEventDestroy(g.ev_done);
+    for (auto& g : c.groups) { hipEventDestroy(g.ev_done); hipEventDestroy(g.ev_tab); }
     if (c.ev_up) hipEventDestroy(c.ev_up);
     if (c.stream) hipStreamDestroy(c.stream);
     if (c.stream2) hipStreamDestroy(c.stream2);
@@ -542,15 +539,16 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
         UHIP(hipEventCreateWithFlags(&gnew.ev_corr, hipEventDisableTiming));
       }
       UHIP(hipEventCreateWithFlags(&gnew.ev_done, hipEventDisableTiming));
+      UHIP(hipEventCreateWithFlags(&gnew.ev_tab, hipEventDisableTiming));
       c.groups.push_back(gnew);
     }
     if (!c.ev_up) UHIP(hipEventCreateWithFlags(&c.ev_up, hipEventDisableTiming));
     UHIP(hipEventRecord(c.ev_up, c.stream));  // inputs, window descriptors and control words are on the device once this fires
-    struct Run { int g0, nw; hipStream_t s, s2; hipEvent_t ev_jac, ev_corr, ev_done; bool active; };
+    struct Run { int g0, nw; hipStream_t s, s2; hipEvent_t ev_jac, ev_corr, ev_done, ev_tab; bool active; };
     std::vector<Run> runs(n_groups);
     for (int g = 0; g < n_groups; ++g) {
       const int a = (int)((long)nw * g / n_groups), b = (int)((long)nw * (g + 1) / n_groups);
-      runs[g] = Run{a, b - a, c.groups[g].s, c.groups[g].s2, c.groups[g].ev_jac, c.groups[g].ev_corr, c.groups[g].ev_done, true};
+      runs[g] = Run{a, b - a, c.groups[g].s, c.groups[g].s2, c.groups[g].ev_jac, c.groups[g].ev_corr, c.groups[g].ev_done, c.groups[g].ev_tab, true};
       if (g > 0) UHIP(hipStreamWaitEvent(runs[g].s, c.ev_up, 0));
     }
     // J^T J launches: one workgroup per (row slice, tile group, window), see ata_kernel
@@ -588,13 +586,15 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       }
       // State correlation at the LPM-initialised state.  The reference assembles the Jacobian synchronously (preint.h:887-937) and
       // hands J^T J, its factorisation and the inverse diagonal to a helper thread that runs beside the two ceres::Solve calls and is
-      // joined before the first get() (preint.h:939, 1062-1065); here the Jacobian is written on the main stream (the fits then change
-      // the states it is evaluated at) and the rest of the chain runs on a second stream that the inference waits for.
-      ug::corr_jac_kernel<<<dim3(ug::kCorrJacParts, r.nw), 256, 0, r.s>>>(dw_);
-      UHIP(hipEventRecord(r.ev_jac, r.s));
-      UHIP(hipStreamWaitEvent(r.s2, r.ev_jac, 0));
+      // joined before the first get() (preint.h:939, 1062-1065).  Here the whole chain, Jacobian included, runs on a second stream
+      // as soon as the kernel tables exist; the Jacobian reads the LPM-initialised states, so the main stream waits for it (ev_jac)
+      // before the first fit writes its solution back (lm_end_kernel), and the inference waits for the end of the chain (ev_corr).
+      UHIP(hipEventRecord(r.ev_tab, r.s));
+      UHIP(hipStreamWaitEvent(r.s2, r.ev_tab, 0));
       {
         Stage st(c, 2, r.s2);
+        ug::corr_jac_kernel<<<dim3(ug::kCorrJacParts, r.nw), 256, 0, r.s2>>>(dw_);
+        UHIP(hipEventRecord(r.ev_jac, r.s2));
         launch_ata(r, 2);
         ug::corr_factor_kernel<<<r.nw, 512, 0, r.s2>>>(dw_);
         ug::corr_diag_kernel<<<dim3((6 * max_S + 15) / 16, r.nw), 256, sizeof(double) * 17 * (6 * max_S + 16), r.s2>>>(dw_);
@@ -643,6 +643,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
         }
       }
       for (size_t g = 0; g < runs.size(); ++g) {
+        if (problem == 0) UHIP(hipStreamWaitEvent(runs[g].s, runs[g].ev_jac, 0));  // corr_jac_kernel has read the initial states
         ug::lm_end_kernel<<<runs[g].nw, 256, 0, runs[g].s>>>(c.d_wins + runs[g].g0, problem, c.d_diag + 4 * (size_t)runs[g].g0);
         st_lm[g].reset();  // stage stop event behind the group's last launch of this problem
       }

@@ -64,6 +64,7 @@ struct UgpmWin {
   double* lhs;    // [3S][3S]
   double* lmv;    // 8 vectors of 3S: g, scale, diag, step, delta, x, x_new, tmp
   double* sample_tmp;  // [max(G,V)][24] per-sample scratch of the evaluators
+  double* sample_tmp_c;  // the same for corr_jac_kernel, which runs beside them on the second stream
   // ---- state correlation (PRE:886-940, 1478-1492)
   double* Jc;      // [(3G+3V)][6S]
   double* Ac;      // [6S][6S]  J^T J + 1e-5 I  -> Cholesky factor L

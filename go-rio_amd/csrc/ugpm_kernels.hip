@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
         double D[3][6];
         jacobian_res(v3(sdot[q][3] + dtm * w.hyper[3], sdot[q][4] + dtm * w.hyper[7], sdot[q][5] + dtm * w.hyper[11]),
                      v3(sdot[q][0] + w.hyper[3], sdot[q][1] + w.hyper[7], sdot[q][2] + w.hyper[11]), D);
-        double* st = w.sample_tmp + (size_t)i * 24;
+        double* st = w.sample_tmp_c + (size_t)i * 24;
         for (int a = 0; a < 3; ++a)
           for (int k = 0; k < 6; ++k) st[a * 6 + k] = D[a][k];
       }
@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
     const int nmine = (G - part + kCorrJacParts - 1) / kCorrJacParts;  // samples of this part
     for (int rr = wave; rr < nmine * 3; rr += 4) {                      // row = (sample, axis a)
       const int i = part + kCorrJacParts * (rr / 3), a = rr % 3;
-      const double* st = w.sample_tmp + (size_t)i * 24;
+      const double* st = w.sample_tmp_c + (size_t)i * 24;
       double* row = J + (size_t)(3 * i + a) * n;
       for (int c = 0; c < 3; ++c) {
         const double f0 = st[a * 6 + c], f1 = st[a * 6 + c + 3];
@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
         const M3 RT = expMap(v3(-rv.x, -rv.y, -rv.z));
         const V3 t = mvec(RT, v3(sdot[q][3] + w.hyper[15], sdot[q][4] + w.hyper[19], sdot[q][5] + w.hyper[23]));
         const M3 dres = mmul(skew(t), Jr(rv));
-        double* st = w.sample_tmp + (size_t)i * 24;
+        double* st = w.sample_tmp_c + (size_t)i * 24;
         storeM(st, dres);
         storeM(st + 9, RT);
       }
@@ -1747,7 +1747,7 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
     const int nmine = (V - part + kCorrJacParts - 1) / kCorrJacParts;
     for (int rr = wave; rr < nmine * 3; rr += 4) {
       const int i = part + kCorrJacParts * (rr / 3), a = rr % 3;
-      const double* st = w.sample_tmp + (size_t)i * 24;
+      const double* st = w.sample_tmp_c + (size_t)i * 24;
       double* row = J + (size_t)(3 * G + 3 * i + a) * n;
       for (int c = 0; c < 3; ++c) {
         const double f0 = wgt * st[a * 3 + c], f1 = wgt * st[9 + a * 3 + c];
