@@ -39,7 +39,7 @@ struct Ctx {  // per-thread, per-device cached buffers
   size_t ws_cap = 0;
   UgpmWin* d_wins = nullptr;
   int wins_cap = 0;
-  int* d_ints = nullptr;  // per window: kWinInts ints (lmi[16], status, ata_cnt[])
+  int* d_ints = nullptr;  // per window: kWinInts ints (lmi[16], status)
   double* d_diag = nullptr;
   // opt.type = LPM windows (ugpm_lpm_out.hip)
   double* lpm_ws = nullptr;
@@ -113,7 +113,6 @@ size_t carve(const gorio_ugpm_window& w, const HostWin& h, UgpmWin& u, double* b
   u.Jrot = take(mrot * n); u.Jvel = take(mvel * n); u.res = take(std::max(mrot, mvel)); u.res_new = take(std::max(mrot, mvel));
   u.JtJ = take(n * n); u.lhs = take(n * n); u.lmv = take(8 * n); u.sample_tmp = take(std::max(G, V) * 24); u.sample_tmp_c = take(std::max(G, V) * 24);
   if (w.correlate) { u.Jc = take(mc * nc); u.Ac = take(nc * nc); }
-  u.ata_part = nullptr;  // (split-K partial tiles: dropped)
   u.dsc = take(nc);
   u.alpha = take(6 * S); u.state_r = take(3 * S); u.d_state_bw = take(3 * S * 3); u.d_d_r_dt = take(3 * S); u.d_vel_bv = take(3 * S * 3); u.d_vel_bw = take(3 * S * 3);
   u.d_vel_dt = take(3 * S); u.out = outp; u.lmc = take(16);
@@ -367,7 +366,6 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     std::memset(&u, 0, sizeof(u));
     u.lmi = c.d_ints + kWinInts * (size_t)i;
     u.status = c.d_ints + kWinInts * (size_t)i + 16;
-    u.ata_cnt = c.d_ints + kWinInts * (size_t)i + 20;
     ints[kWinInts * (size_t)i + 16] = h.status;
     u.n_infer = std::max(0, w.n_infer);
     out_offs[i] = out_off;
@@ -559,7 +557,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       const int tpg = which == 2 ? kAtaTilesCorr : kAtaTilesLm;
       const int ng = (ntile + tpg - 1) / tpg;
       const int npad = ((n + 15) / 32) * 32 + 16;
-      const int units = r.nw * ng, grid = ((units + 7) / 8) * kAtaKSplit * 8;
+      const int units = r.nw * ng, grid = ((units + 7) / 8) * 8;
       const UgpmWin* dw_ = c.d_wins + r.g0;
       // LDS as small as the staging needs (53 KB at n = 198): the scan matcher's kernels share the CUs with these workgroups
       auto lds = [&](int kc) { return sizeof(double) * 2 * kc * (npad + 1); };

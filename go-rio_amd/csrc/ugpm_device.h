@@ -8,10 +8,8 @@
 
 namespace gorio {
 
-constexpr int kAtaKSplit = 1;       // workgroups sharing the rows of J for one group of output tiles
 constexpr int kAtaTilesLm = 24, kAtaTilesCorr = 48;  // 16 x 16 output tiles per workgroup (8 waves x 4 / 6 accumulators)
-constexpr int kAtaMaxGroups = 28;
-constexpr int kWinInts = 48;        // ints per window: lmi[16], status at 16, ata_cnt at 20
+constexpr int kWinInts = 48;        // ints per window: lmi[16], status at 16
 constexpr int kVelBlocks = 3;       // problem #2's normal matrix is block diagonal (one block per velocity channel): lm_step_kernel runs one workgroup per block
 
 struct UgpmWin {
@@ -84,10 +82,6 @@ struct UgpmWin {
                 // 11..13 squared step norm of the (up to three) diagonal blocks lm_step_kernel solved
   int* lmi;     // [16]: 0 iter, 1 done, 2 reuse_diag, 3 need_J, 4 step_valid, 5 termination, 6 successful, 7 problem (0 rot, 1 vel)
   int* status;  // [1] per-window gorio_ugpm_status
-  // J^T J split over workgroups (ata_kernel): partial tiles [kAtaKSplit][tiles][256] followed by partial gradients [kAtaKSplit][n],
-  // and one arrival counter per tile group (zero between launches)
-  double* ata_part;
-  int* ata_cnt;  // [kAtaMaxGroups]
 };
 
 }  // namespace gorio

@@ -1781,8 +1781,7 @@ template <int CMAX, int KC, int TPG>
 __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wins, int which, int n_windows, int groups_max) {
   const int L = blockIdx.x;
   const int xcd = L & 7, pslot = L >> 3;
-  const int ks = pslot % kAtaKSplit;
-  const int unit = (pslot / kAtaKSplit) * 8 + xcd;
+  const int unit = pslot * 8 + xcd;
   const int win = unit / groups_max, grp = unit % groups_max;
   if (win >= n_windows) return;
   const UgpmWin w = load_win(wins, win);
@@ -1808,7 +1807,7 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
   const int q_lo = (int)((long)grp * ntile / ng), q_hi = (int)((long)(grp + 1) * ntile / ng);
   const int npad = ata_npad(n);
   const int nck = (m + KC - 1) / KC;
-  const int c_lo = ks * nck / kAtaKSplit, c_hi = (ks + 1) * nck / kAtaKSplit;
+  const int c_lo = 0, c_hi = nck;
   extern __shared__ double ata_lds[];  // [2][KC][npad] staged rows of A, then [2][KC] staged entries of r
   double* rl = ata_lds + (size_t)2 * KC * npad;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1902,7 +1901,6 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
     __syncthreads();
     CHOL_T(4);
   }
-  static_assert(kAtaKSplit == 1, "a split of the rows over workgroups (partial tiles + ordered reduction) was measured and dropped");
   {  // this workgroup saw every row: its accumulators ARE the result
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

@@ -33,17 +33,16 @@ int main(int argc, char** argv) {
     UgpmWin& u = hw[i];
     memset(&u, 0, sizeof u);
     u.S = S; u.G = G; u.V = G;
-    u.lmi = ints + kWinInts * (size_t)i; u.status = u.lmi + 16; u.ata_cnt = u.lmi + 20;
+    u.lmi = ints + kWinInts * (size_t)i; u.status = u.lmi + 16;
     u.Jrot = dJ + (size_t)i * J.size(); u.res = dr;
     hipMalloc(&u.JtJ, (size_t)n * n * 8);
     hipMalloc(&u.lmv, (size_t)8 * n * 8);
-    hipMalloc(&u.ata_part, (size_t)kAtaKSplit * ((size_t)ntile * 256 + n) * 8);
   }
   UgpmWin* dw;
   hipMalloc(&dw, sizeof(UgpmWin) * nw);
   hipMemcpy(dw, hw.data(), sizeof(UgpmWin) * nw, hipMemcpyHostToDevice);
   const int npad = ((n + 15) / 32) * 32 + 16;
-  const int units = nw * ng, grid = ((units + 7) / 8) * kAtaKSplit * 8;
+  const int units = nw * ng, grid = ((units + 7) / 8) * 8;
   const size_t lds = sizeof(double) * 2 * 16 * (npad + 1);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&ata_kernel<4, 16, kAtaTilesLm>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&ata_kernel<8, 16, kAtaTilesLm>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
