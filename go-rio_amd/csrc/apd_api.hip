@@ -1710,6 +1710,62 @@ int gorio_prep_dbscan_labels(int device, const float* xyz, int n, int point_stri
   return GORIO_OK;
 }
 
+int gorio_prep_radius_outlier_mask(int device, const float* xyz, int n, int point_stride_bytes, double radius, int min_neighbors, unsigned char* keep, int* n_kept) {
+  if (!xyz || !keep || n <= 0 || point_stride_bytes < 12 || (point_stride_bytes % 4) || !(radius > 0.0) || min_neighbors < 0)
+    return prep_fail(GORIO_ERR_INVALID, "radius_outlier_mask: bad arguments");
+  PrepCtx& c = g_prep;
+  if (!c.h || c.device != device) {
+    if (c.h) {
+      hipSetDevice(c.device);
+      hipFree(c.d_cnt); hipFree(c.d_offs); hipFree(c.d_adj);
+      gorio_apd_destroy(c.h);
+      c = PrepCtx();
+    }
+    const int rc = gorio_apd_create(&c.h, device);
+    if (rc) return prep_fail(rc, "radius_outlier_mask: no usable HIP device (there is no CPU fallback)");
+    c.device = device;
+  }
+  gorio_apd* h = c.h;
+  h->params.search = GORIO_SEARCH_PRUNED;
+  int rc = gorio_apd_set_source(h, xyz, nullptr, n, point_stride_bytes);
+  if (rc) return prep_fail(rc, h->err);
+  {
+    std::vector<std::pair<gorio_apd*, DevCloud*>> one = {{h, h->src.get()}};
+    rc = run_index_build(h, one);
+    if (rc) return prep_fail(rc, h->err);
+  }
+  auto hip_fail = [&](const char* what, hipError_t e) { return prep_fail(GORIO_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+  if ((size_t)n > c.pts_cap) {
+    hipFree(c.d_cnt); hipFree(c.d_offs);
+    c.d_cnt = nullptr; c.d_offs = nullptr;
+    c.pts_cap = 0;
+    hipError_t e = hipMalloc(&c.d_cnt, sizeof(int) * ((size_t)n + n / 8));
+    if (e == hipSuccess) e = hipMalloc(&c.d_offs, sizeof(long long) * ((size_t)n + n / 8));
+    if (e != hipSuccess) return hip_fail("hipMalloc", e);
+    c.pts_cap = (size_t)n + n / 8;
+  }
+  const double r2d = radius * radius;
+  float r2 = FLT_MAX;
+  if (r2d < (double)FLT_MAX) {  // largest float whose double value is <= r^2: (double)d <= r^2  <=>  d <= r2 for every float d
+    r2 = (float)r2d;
+    while ((double)r2 > r2d) r2 = std::nextafterf(r2, 0.0f);
+  }
+  radius_count_kernel<<<(roundup(n, 512) + 255) / 256, 256, 0, h->stream>>>(h->src->view(), r2, c.d_cnt);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail("radius_count_kernel", e);
+  std::vector<int> cnt((size_t)n);
+  e = hipMemcpyAsync(cnt.data(), c.d_cnt, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return hip_fail("download", e);
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    keep[i] = cnt[i] > min_neighbors ? 1 : 0;  // the query itself is one of the counted points
+    kept += keep[i];
+  }
+  if (n_kept) *n_kept = kept;
+  return GORIO_OK;
+}
+
 }  // extern "C"
 
 // ----------------------------------------------------------------------------------------------- REVE (include/gorio_prep.h)

@@ -78,6 +78,47 @@ __global__ __launch_bounds__(256) void radius_neighbours_kernel(CloudView cloud,
   if (MODE == 0 && p < n) a.cnt[me] = cnt;
 }
 
+// pcl::RadiusOutlierRemoval as the preprocessing nodelet configures it (preprocessing_nodelet_ntu.cpp:163-171, 626-634; launch files:
+// radius 2 m, 1 - 5 neighbours): number of points of the SAME cloud, the query included, whose float squared distance is at most the
+// squared radius.  r2 = largest float whose double value is <= radius * radius (the comparison PCL makes is in double on float
+// distances).  grid: ceil(n_spad / 256), block 256; cnt[] by ORIGINAL index.
+__global__ __launch_bounds__(256) void radius_count_kernel(CloudView cloud, float r2, int* __restrict__ cnt_out) {
+  const SearchIndex& si = cloud.idx;
+  const int n = si.n;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int pq = p < n ? p : n - 1;
+  const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
+  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
+  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
+  const scalar_fp tx = as_scalar(si.sx);
+  const scalar_fp ty = as_scalar(si.sy);
+  const scalar_fp tz = as_scalar(si.sz);
+  const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
+  const int ng = (si.n_tiles + 63) / 64;
+  int cnt = 0;
+  for (int g = 0; g < ng; ++g) {
+    const int tl = g * 64 + lane;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    if (tl < si.n_tiles) {
+      lo = tb4[2 * (size_t)tl];
+      hi = tb4[2 * (size_t)tl + 1];
+    }
+    unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= r2);
+    while (mask) {
+      const int tlane = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+      if (__ballot(box_bound(qx, qy, qz, bx) <= r2) == 0) continue;
+      const int j0 = (g * 64 + tlane) * 32;
+#pragma unroll 4
+      for (int u = 0; u < 32; ++u) cnt += sqdist3(qx, qy, qz, tx[j0 + u], ty[j0 + u], tz[j0 + u]) <= r2 ? 1 : 0;  // padding points: d = inf
+    }
+  }
+  if (p < n) cnt_out[si.orig[p]] = cnt;
+}
+
 }  // namespace gorio
 
 // ----------------------------------------------------------------------------------------------- REVE Doppler ego-velocity

@@ -29,6 +29,14 @@ int gorio_prep_dbscan_labels(int device, const float* xyz, int n, int point_stri
                              float* label_out, int label_stride_bytes, int* n_clusters);
 
 /*
+ * pcl::RadiusOutlierRemoval as preprocessing_nodelet_ntu.cpp:163-171, 626-634 configures it (launch files: radius_radius 2,
+ * radius_min_neighbors 1 - 5): keep[i] = 1 when MORE than min_neighbors points of the cloud, the point itself included, lie within
+ * `radius` of point i (float squared distance compared with radius^2 in double, as PCL 1.10 does on its nearestKSearch results).
+ * The caller compacts the cloud with the mask (pcl::Filter::filter keeps the surviving points in their original order).
+ */
+int gorio_prep_radius_outlier_mask(int device, const float* xyz, int n, int point_stride_bytes, double radius, int min_neighbors, unsigned char* keep, int* n_kept);
+
+/*
  * REVE Doppler ego-velocity (REVE = src/radar_ego_velocity_estimator.cpp, REVEH = include/radar_ego_velocity_estimator.h):
  * RadarEgoVelocityEstimator::estimate (REVE:60-170) -- per-target gates, zero-velocity test, 3-D least squares with RANSAC
  * (REVE:172-250, 252-303).  The velocities it produces are the `vel` samples of the GP pre-integration windows

@@ -226,6 +226,15 @@ def dbscan_labels(xyz, eps=0.9, min_pts=10, min_cluster=20, max_cluster=25000):
     return lab[:n].copy(), int(nc)
 
 
+def radius_outlier_mask(xyz, radius=2.0, min_pts=2):
+    """pcl::RadiusOutlierRemoval (preprocessing_nodelet_ntu.cpp:163-171): boolean keep mask."""
+    xyz = _f32(xyz)
+    n = xyz.shape[0]
+    keep = np.zeros(max(n, 1), np.uint8)
+    lib().apdo_radius_outlier_mask(_p(xyz, C.c_float), n, C.c_double(radius), int(min_pts), _p(keep, C.c_ubyte))
+    return keep[:n].astype(bool)
+
+
 class ReveConfig(C.Structure):
     """apdo_reve_config == RadarEgoVelocityEstimatorConfig (radar_ego_velocity_estimator.h:30-60), the fields the estimator reads."""
     _fields_ = [(k, C.c_float) for k in (

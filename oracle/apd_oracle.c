@@ -1115,6 +1115,28 @@ int apdo_submap_assemble(const float* xyz /* all frames, packed n x 3 */, const 
   return n_out;
 }
 
+/*
+ * pcl::RadiusOutlierRemoval as the preprocessing nodelet uses it (PREP:163-171, 626-634; radius_radius / radius_min_neighbors of the
+ * launch files).  PCL 1.10 (dense input): nearestKSearch(point, min_pts + 1) on the cloud itself -- the query is its own nearest
+ * neighbour at distance 0 -- and the point is kept unless fewer than min_pts + 1 neighbours exist or radius^2 < (float) squared
+ * distance of the last one (compared in double).  Restated without the tree: keep <=> the number of points j, i included, with
+ * (double) d2(i, j) <= radius * radius exceeds min_pts.  "Parity unpinned": PCL is not under /root/reference.  keep_out[n]; returns
+ * the number of points kept.
+ */
+int apdo_radius_outlier_mask(const float* xyz, int n, double radius, int min_pts, unsigned char* keep_out) {
+  const double r2 = radius * radius;
+  int kept = 0;
+#pragma omp parallel for schedule(static) reduction(+ : kept)
+  for (int i = 0; i < n; ++i) {
+    int cnt = 0;
+    for (int j = 0; j < n; ++j)
+      if ((double)sqdist3f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]) <= r2) ++cnt;
+    keep_out[i] = cnt > min_pts ? 1 : 0;
+    kept += keep_out[i];
+  }
+  return kept;
+}
+
 /* ------------------------------------------------------------------------------------------------ preprocessing: DBSCAN cluster labels
  *
  * PREP = /root/reference/4DRadarSLAM/apps/preprocessing_nodelet_ntu.cpp, DBS = /root/reference/4DRadarSLAM/include/dbscan/DBSCAN_simple.h.

@@ -137,3 +137,42 @@ def test_reve_ego_velocity_matches_oracle(gpu, gorio, oracle_apd, case):
         assert ro["inlier"].sum() == ro["n_valid"] and ro["outlier"].sum() == 0
     if case == "moving":
         assert np.allclose(rg["v_r"], [5.2, -0.3, 0.1], atol=0.02)
+
+
+# ------------------------------------------------------------------------------------------------ radius outlier removal
+
+def test_oracle_radius_outlier_mask_against_kdtree_counts(oracle_apd):
+    """CPU: the restatement against an independent neighbour count (scipy cKDTree on the float coordinates; pairs within 2e-5 m of the
+    radius are excluded from the comparison: the tree measures in double, the restatement on FLANN's float distances)."""
+    from scipy.spatial import cKDTree
+
+    xyz, _ = synth.radar_scan(6000, seed=synth.BASE_SEED + 61)
+    tree = cKDTree(xyz.astype(np.float64))
+    for radius, min_pts in ((2.0, 2), (2.0, 5), (0.8, 1)):
+        keep = oracle_apd.radius_outlier_mask(xyz, radius, min_pts)
+        lo = np.array([len(v) for v in tree.query_ball_point(xyz.astype(np.float64), radius - 2e-5)])
+        hi = np.array([len(v) for v in tree.query_ball_point(xyz.astype(np.float64), radius + 2e-5)])
+        sure = lo == hi
+        assert sure.mean() > 0.95
+        assert np.array_equal(keep[sure], lo[sure] > min_pts)
+        assert 0 < keep.sum() < len(xyz)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("radius,min_pts", [(2.0, 2), (2.0, 5), (0.8, 1), (5.0, 40)])
+def test_radius_outlier_mask_matches_oracle(gpu, gorio, oracle_apd, radius, min_pts):
+    """pcl::RadiusOutlierRemoval with the launch files' parameters (radius 2, 1 - 5 neighbours) and two others: the GPU mask equals the
+    CPU restatement exactly (both count float L2_Simple squared distances <= radius^2)."""
+    for seed, n in ((62, 16384), (63, 3000), (64, 257)):
+        xyz, _ = synth.radar_scan(n, seed=synth.BASE_SEED + seed)
+        keep = gorio.prep.radius_outlier_mask(xyz, radius, min_pts)
+        assert np.array_equal(keep, oracle_apd.radius_outlier_mask(xyz, radius, min_pts))
+
+
+@pytest.mark.gpu
+def test_radius_outlier_mask_counts_duplicates_and_isolated_points(gpu, gorio, oracle_apd):
+    xyz = np.array([[0, 0, 0], [0, 0, 0], [0, 0, 0], [10, 0, 0], [10.5, 0, 0], [50, 50, 5]], np.float32)
+    xyz = np.concatenate([xyz, np.array([[100 + 0.1 * i, -20, 1] for i in range(40)], np.float32)])
+    keep = gorio.prep.radius_outlier_mask(xyz, 1.0, 2)
+    assert np.array_equal(keep, oracle_apd.radius_outlier_mask(xyz, 1.0, 2))
+    assert keep[:3].all() and not keep[3] and not keep[4] and not keep[5]  # three coincident points count each other; a pair is one short
