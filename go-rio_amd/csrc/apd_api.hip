@@ -1766,6 +1766,40 @@ int gorio_prep_radius_outlier_mask(int device, const float* xyz, int n, int poin
   return GORIO_OK;
 }
 
+int gorio_prep_voxel_downsample(int device, const float* xyz, int n, int point_stride_bytes, double leaf, float* xyz_out, int out_stride_bytes, int out_capacity, int* n_out) {
+  if (!xyz || !xyz_out || !n_out || n <= 0 || point_stride_bytes < 12 || (point_stride_bytes % 4) || out_stride_bytes < 12 || (out_stride_bytes % 4) || !(leaf > 0.0))
+    return prep_fail(GORIO_ERR_INVALID, "voxel_downsample: bad arguments");
+  PrepCtx& c = g_prep;
+  if (!c.h || c.device != device) {
+    if (c.h) {
+      hipSetDevice(c.device);
+      hipFree(c.d_cnt); hipFree(c.d_offs); hipFree(c.d_adj);
+      gorio_apd_destroy(c.h);
+      c = PrepCtx();
+    }
+    const int rc = gorio_apd_create(&c.h, device);
+    if (rc) return prep_fail(rc, "voxel_downsample: no usable HIP device (there is no CPU fallback)");
+    c.device = device;
+  }
+  // the scan-to-submap assembly with ONE frame and the identity pose is exactly pcl::VoxelGrid on that cloud (the float transform by
+  // the identity returns every coordinate unchanged)
+  const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  gorio_apd_keyframe fr;
+  fr.xyz = xyz;
+  fr.label = nullptr;
+  fr.n = n;
+  fr.point_stride_bytes = point_stride_bytes;
+  fr.rel_pose = eye;
+  int m = 0;
+  int rc = gorio_apd_set_target_submap(c.h, &fr, 1, leaf, &m);
+  if (rc) return prep_fail(rc, c.h->err);
+  *n_out = m;
+  if (m > out_capacity) return prep_fail(GORIO_ERR_INVALID, "voxel_downsample: output capacity too small (n_out holds the size needed)");
+  rc = gorio_apd_get_target_points(c.h, xyz_out, nullptr, m, out_stride_bytes);
+  if (rc) return prep_fail(rc, c.h->err);
+  return GORIO_OK;
+}
+
 }  // extern "C"
 
 // ----------------------------------------------------------------------------------------------- REVE (include/gorio_prep.h)

@@ -5,7 +5,7 @@ import numpy as np
 
 from .apd import GorioError, load_library
 
-PREP_SYMBOLS = ["gorio_prep_dbscan_labels", "gorio_prep_radius_outlier_mask", "gorio_prep_last_error", "gorio_prep_reve_default_config", "gorio_prep_reve_ransac_iterations", "gorio_prep_ego_velocity"]
+PREP_SYMBOLS = ["gorio_prep_dbscan_labels", "gorio_prep_radius_outlier_mask", "gorio_prep_voxel_downsample", "gorio_prep_last_error", "gorio_prep_reve_default_config", "gorio_prep_reve_ransac_iterations", "gorio_prep_ego_velocity"]
 
 
 def dbscan_labels(xyz, eps=0.9, core_min_pts=10, min_cluster_size=20, max_cluster_size=25000, device=0):
@@ -24,6 +24,21 @@ def dbscan_labels(xyz, eps=0.9, core_min_pts=10, min_cluster_size=20, max_cluste
         msg = lib.gorio_prep_last_error()
         raise GorioError(rc, msg.decode() if msg else "")
     return lab, nc.value
+
+
+def voxel_downsample(xyz, leaf=0.1, device=0):
+    """pcl::VoxelGrid (preprocessing_nodelet_ntu.cpp:137-139, 608-622): centroids [m,3], ordered by voxel index."""
+    lib = load_library()
+    lib.gorio_prep_last_error.restype = C.c_char_p
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = xyz.shape[0]
+    out = np.zeros((n, 3), np.float32)
+    m = C.c_int(0)
+    rc = lib.gorio_prep_voxel_downsample(int(device), C.c_void_p(xyz.__array_interface__["data"][0]), n, 12, C.c_double(leaf), C.c_void_p(out.__array_interface__["data"][0]), 12, n, C.byref(m))
+    if rc < 0:
+        msg = lib.gorio_prep_last_error()
+        raise GorioError(rc, msg.decode() if msg else "")
+    return out[:m.value].copy()
 
 
 def radius_outlier_mask(xyz, radius=2.0, min_neighbors=2, device=0):

@@ -37,6 +37,15 @@ int gorio_prep_dbscan_labels(int device, const float* xyz, int n, int point_stri
 int gorio_prep_radius_outlier_mask(int device, const float* xyz, int n, int point_stride_bytes, double radius, int min_neighbors, unsigned char* keep, int* n_kept);
 
 /*
+ * pcl::VoxelGrid as the preprocessing nodelet applies it to every scan (preprocessing_nodelet_ntu.cpp:137-139, 608-622; launch files:
+ * downsample_method VOXELGRID, downsample_resolution 0.1): one output point per occupied voxel = the centroid of its points, output
+ * ordered by voxel index as PCL's sorted index vector yields it.  Only the coordinates are produced: they are all the hot path reads
+ * at this stage (normal_x is written later, by the DBSCAN step).  Runs the device voxel grid of gorio_apd_set_target_submap.
+ * n_out receives the number of voxels even when out_capacity is too small.
+ */
+int gorio_prep_voxel_downsample(int device, const float* xyz, int n, int point_stride_bytes, double leaf, float* xyz_out, int out_stride_bytes, int out_capacity, int* n_out);
+
+/*
  * REVE Doppler ego-velocity (REVE = src/radar_ego_velocity_estimator.cpp, REVEH = include/radar_ego_velocity_estimator.h):
  * RadarEgoVelocityEstimator::estimate (REVE:60-170) -- per-target gates, zero-velocity test, 3-D least squares with RANSAC
  * (REVE:172-250, 252-303).  The velocities it produces are the `vel` samples of the GP pre-integration windows

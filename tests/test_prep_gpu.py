@@ -176,3 +176,17 @@ def test_radius_outlier_mask_counts_duplicates_and_isolated_points(gpu, gorio, o
     keep = gorio.prep.radius_outlier_mask(xyz, 1.0, 2)
     assert np.array_equal(keep, oracle_apd.radius_outlier_mask(xyz, 1.0, 2))
     assert keep[:3].all() and not keep[3] and not keep[4] and not keep[5]  # three coincident points count each other; a pair is one short
+
+
+# ------------------------------------------------------------------------------------------------ voxel-grid downsampling
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("leaf", [0.1, 0.5, 2.0])
+def test_voxel_downsample_matches_oracle(gpu, gorio, oracle_apd, leaf):
+    """pcl::VoxelGrid of one scan (the preprocessing nodelet's downsample step, leaf 0.1 in the launch files): the device voxel grid
+    against the CPU restatement of PCL's centroid rule -- same voxels, same order, centroids to float rounding."""
+    xyz, _ = synth.radar_scan(16384, seed=synth.BASE_SEED + 71)
+    out = gorio.prep.voxel_downsample(xyz, leaf)
+    ref, _ = oracle_apd.submap_assemble([(xyz, np.zeros(len(xyz), np.float32))], [np.eye(4)], leaf)
+    assert out.shape == ref.shape and out.shape[0] < len(xyz)
+    assert np.abs(out - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
