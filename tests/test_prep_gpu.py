@@ -190,3 +190,37 @@ def test_voxel_downsample_matches_oracle(gpu, gorio, oracle_apd, leaf):
     ref, _ = oracle_apd.submap_assemble([(xyz, np.zeros(len(xyz), np.float32))], [np.eye(4)], leaf)
     assert out.shape == ref.shape and out.shape[0] < len(xyz)
     assert np.abs(out - ref).max() < 1e-6 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------------ the chain that feeds the registration
+
+@pytest.mark.gpu
+def test_preprocessing_chain_then_registration_matches_oracle(gpu, gorio, oracle_apd, pose_err):
+    """What the preprocessing nodelet does to a scan before the registration sees it (PREP:503-568: VoxelGrid -> RadiusOutlierRemoval
+    -> DBSCAN labels into normal_x), on the GPU and through the CPU restatements, for two scans of one scene; then APD-GICP on the two
+    results (the labels feed its cluster weight, APD:271-273).  Every stage must agree: same voxels, same mask, same labels, and the
+    registration within 1e-4 of the oracle's on the GPU-made inputs."""
+    sx, _, tx, _, _ = synth.scan_pair(16384, 16384, seed=synth.BASE_SEED + 81)
+    made = []
+    for raw in (sx, tx):
+        v_g = gorio.prep.voxel_downsample(raw, 0.3)
+        v_o, _ = oracle_apd.submap_assemble([(raw, np.zeros(len(raw), np.float32))], [np.eye(4)], 0.3)
+        assert v_g.shape == v_o.shape and np.abs(v_g - v_o).max() < 1e-5
+        k_g = gorio.prep.radius_outlier_mask(v_g, 2.0, 2)
+        assert np.array_equal(k_g, oracle_apd.radius_outlier_mask(v_g, 2.0, 2))
+        pts = np.ascontiguousarray(v_g[k_g])
+        l_g, nc = gorio.prep.dbscan_labels(pts)
+        l_o, nc_o = oracle_apd.dbscan_labels(pts)
+        assert nc == nc_o and np.array_equal(l_g, l_o)
+        made.append((pts, l_g))
+    (a, la), (b, lb) = made
+    assert 3000 < len(a) < 16384 and la.max() >= 1
+    p = oracle_apd.launch_params()
+    ca, cb = oracle_apd.calculate_covariances(a, p), oracle_apd.calculate_covariances(b, p)
+    ro = oracle_apd.align(np.eye(4), a, la, b, lb, ca, cb, p)
+    g = gorio.ApdGicp(corr_dist_threshold=2.0, transformation_epsilon=0.1, search=1)
+    g.setInputTarget(b, lb)
+    g.setInputSource(a, la)
+    r = g.align()
+    te, re = pose_err(ro["T"], r["T"])
+    assert te < 1e-4 and re < 1e-4 and r["converged"] == ro["converged"] and r["n_linearize"] == ro["n_linearize"]
