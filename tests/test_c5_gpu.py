@@ -95,3 +95,26 @@ def test_c5_shared_map_equals_private_copy(gpu, gorio, c5):
     ca, _ = shared.getCorrespondences()
     cb, _ = private.getCorrespondences()
     assert np.array_equal(ca, cb)
+
+
+def test_pruned_search_on_a_target_beyond_one_mask_pass(gpu, gorio):
+    """The group mask of the three-level search covers 2048 tile groups (4.2 M points) per pass; a 4.5 M-point target needs two passes.
+    Exhaustive and pruned search must still agree bit for bit (correspondences, squared distances) -- covariances are injected so that
+    only the searches run at this size."""
+    rng = np.random.default_rng(7)
+    m = 4_500_000
+    tx = np.stack([rng.uniform(0, 400, m), rng.uniform(-200, 200, m), rng.uniform(-3, 12, m)], axis=1).astype(np.float32)
+    sx = (tx[rng.choice(m, 4096, replace=False)] + rng.normal(0, 0.3, (4096, 3))).astype(np.float32)
+    g = gorio.ApdGicp(corr_dist_threshold=2.0, search=1)
+    g.setInputTarget(tx, np.zeros(m, np.float32))
+    g.setInputSource(sx, np.zeros(4096, np.float32))
+    g.setTargetCovariances(np.tile(np.eye(4), (m, 1, 1)))
+    g.setSourceCovariances(np.tile(np.eye(4), (4096, 1, 1)))
+    _, H_p, b_p = g.linearize(np.eye(4))
+    corr_p, sqd_p = g.getCorrespondences()
+    g.set_params(search=0)
+    _, H_b, b_b = g.linearize(np.eye(4))
+    corr_b, sqd_b = g.getCorrespondences()
+    assert (corr_b >= 0).sum() > 3000
+    assert np.array_equal(corr_p, corr_b) and np.array_equal(sqd_p[corr_p >= 0], sqd_b[corr_b >= 0])
+    assert np.array_equal(H_p, H_b) and np.array_equal(b_p, b_b)
