@@ -224,3 +224,35 @@ def test_preprocessing_chain_then_registration_matches_oracle(gpu, gorio, oracle
     r = g.align()
     te, re = pose_err(ro["T"], r["T"])
     assert te < 1e-4 and re < 1e-4 and r["converged"] == ro["converged"] and r["n_linearize"] == ro["n_linearize"]
+
+
+# ------------------------------------------------------------------------------------------------ ego-velocity -> pre-integration
+
+@pytest.mark.gpu
+def test_ego_velocity_samples_feed_the_preintegration(gpu, gorio, oracle_apd):
+    """The other feeder of the hot path: every radar scan's Doppler ego-velocity becomes one `vel` sample of the pre-integration window
+    (radar_graph_slam_nodelet.cpp:274-280, 481-495).  A 20 Hz train of synthetic scans along the IMU generator's velocity profile is
+    estimated on the GPU and by the CPU restatement with the same RANSAC draws; the GPU-made samples then go through UGPM on both
+    sides.  Every estimate agrees to 1e-10, the pre-integrated window to the usual gates."""
+    win = synth.imu_window(seed=synth.BASE_SEED + 91, vel_hz=20.0)
+    cfg_g, cfg_o = gorio.prep.reve_default_config(), oracle_apd.reve_default_config()
+    vel = []
+    for k, t_k in enumerate(win["vel_t"]):
+        v_true = synth.vel_true(np.array([t_k]))[0]
+        targets, rng = _radar_targets(100 + k, n=1500, v_true=tuple(v_true), noise=0.03, movers=40)
+        nv = gorio.prep.ego_velocity(targets, [], cfg_g)["n_valid"]
+        samples = rng.integers(0, max(nv, 1), (3, 5)).astype(np.uint32)
+        rg, ro = gorio.prep.ego_velocity(targets, samples, cfg_g), oracle_apd.reve_estimate(targets, samples, cfg_o)
+        assert rg["success"] and ro["success"] and np.allclose(rg["v_r"], ro["v_r"], rtol=1e-10, atol=1e-12)
+        assert abs(rg["v_r"][0] - v_true[0]) < 0.05  # forward speed; lateral / vertical speed are weakly observable in this field of view
+        vel.append(rg["v_r"])
+    import oracle
+    from oracle import ugpm as oracle_ugpm
+
+    oracle.build()
+    win = dict(win, vel=np.ascontiguousarray(np.stack(vel)))
+    mg = gorio.ugpm_preint_batch([win], state_freq=20.0)[0][0]
+    mo = oracle_ugpm.preintegrate(win, state_freq=20.0)[0][0]
+    dR = mo["delta_R"].T @ mg["delta_R"]
+    ang = float(np.arccos(np.clip((np.trace(dR) - 1.0) / 2.0, -1.0, 1.0)))
+    assert ang < 1e-6 and np.linalg.norm(mg["delta_p"] - mo["delta_p"]) < 1e-6
