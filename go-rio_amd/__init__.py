@@ -12,7 +12,7 @@ The directory name contains a hyphen, so import it with
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgorio_amd.so")
+LIB_PATH = os.environ.get("GORIO_AMD_LIB") or os.path.join(_HERE, "lib", "libgorio_amd.so")  # GORIO_AMD_LIB: a variant build (development A/B runs)
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 

@@ -50,7 +50,7 @@ struct DevCloud {
   bool present = false;
   int cov_count = 0;       // == source_covs_.size(): n when valid, 0 when stale
   // exact search accelerator (GORIO_SEARCH_PRUNED)
-  SearchIndex idx = SearchIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  SearchIndex idx = SearchIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   unsigned long long* keys = nullptr;
   unsigned int* bb = nullptr;
   int idx_cap = 0, keys_cap = 0;
@@ -72,6 +72,7 @@ struct gorio_apd {
   std::shared_ptr<DevCloud> src, tgt;  // never null; tgt may be shared with other handles of the device
   // per-source-point state
   unsigned long long* best_key = nullptr;
+  int* seed = nullptr;     // warm start of the pruned search, by sorted source position (PairDesc::seed)
   int* corr = nullptr;
   float* sqd = nullptr;
   double* omega6 = nullptr;
@@ -187,7 +188,7 @@ Rccl& rccl() {
 DevCloud::~DevCloud() {
   DevCloud& c = *this;
   hipSetDevice(c.device);
-  hipFree(c.idx.sx); hipFree(c.idx.sy); hipFree(c.idx.sz); hipFree(c.idx.orig); hipFree(c.idx.tbox); hipFree(c.idx.sbox); hipFree(c.keys); hipFree(c.bb);
+  hipFree(c.idx.sx); hipFree(c.idx.sy); hipFree(c.idx.sz); hipFree(c.idx.orig); hipFree(c.idx.s4); hipFree(c.idx.tbox); hipFree(c.idx.sbox); hipFree(c.idx.bbox); hipFree(c.keys); hipFree(c.bb);
   hipFree(c.x); hipFree(c.y); hipFree(c.z); hipFree(c.label); hipFree(c.p4); hipFree(c.cov6); hipFree(c.geo_w); hipFree(c.knn); hipFree(c.part_d); hipFree(c.part_i); hipFree(c.redo); hipFree(c.kth);
 }
 namespace {
@@ -222,10 +223,11 @@ int ensure_cloud(gorio_apd* h, DevCloud& c, int n) {
 
 int ensure_points(gorio_apd* h, int n) {
   if (n > h->pt_cap) {
-    hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
-    h->best_key = nullptr; h->corr = nullptr; h->sqd = nullptr; h->omega6 = nullptr; h->partials = nullptr;
+    hipFree(h->best_key); hipFree(h->seed); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
+    h->best_key = nullptr; h->seed = nullptr; h->corr = nullptr; h->sqd = nullptr; h->omega6 = nullptr; h->partials = nullptr;
     const int cap = n + n / 8 + 256;
     HIP_TRY(h, hipMalloc(&h->best_key, sizeof(unsigned long long) * cap));
+    HIP_TRY(h, hipMalloc(&h->seed, sizeof(int) * (cap + 512)));  // indexed by sorted position < roundup(n, 512)
     HIP_TRY(h, hipMalloc(&h->corr, sizeof(int) * cap));
     HIP_TRY(h, hipMalloc(&h->sqd, sizeof(float) * cap));
     HIP_TRY(h, hipMalloc(&h->omega6, sizeof(double) * 6 * cap));
@@ -417,15 +419,17 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     int npow2 = kSortTile;
     while (npow2 < c.n) npow2 <<= 1;
     if (n_spad > c.idx_cap) {
-      hipFree(c.idx.sx); hipFree(c.idx.sy); hipFree(c.idx.sz); hipFree(c.idx.orig); hipFree(c.idx.tbox); hipFree(c.idx.sbox);
-      c.idx.sx = c.idx.sy = c.idx.sz = nullptr; c.idx.orig = nullptr; c.idx.tbox = c.idx.sbox = nullptr;
+      hipFree(c.idx.sx); hipFree(c.idx.sy); hipFree(c.idx.sz); hipFree(c.idx.orig); hipFree(c.idx.s4); hipFree(c.idx.tbox); hipFree(c.idx.sbox); hipFree(c.idx.bbox);
+      c.idx.sx = c.idx.sy = c.idx.sz = nullptr; c.idx.orig = nullptr; c.idx.s4 = nullptr; c.idx.tbox = c.idx.sbox = c.idx.bbox = nullptr;
       const int cap = n_spad + roundup(n_spad / 8, 512);
       HIP_TRY(h, hipMalloc(&c.idx.sx, sizeof(float) * cap));
       HIP_TRY(h, hipMalloc(&c.idx.sy, sizeof(float) * cap));
       HIP_TRY(h, hipMalloc(&c.idx.sz, sizeof(float) * cap));
       HIP_TRY(h, hipMalloc(&c.idx.orig, sizeof(int) * cap));
+      HIP_TRY(h, hipMalloc(&c.idx.s4, sizeof(float4) * cap));
       HIP_TRY(h, hipMalloc(&c.idx.tbox, sizeof(float) * 8 * (cap / 32)));
       HIP_TRY(h, hipMalloc(&c.idx.sbox, sizeof(float) * 8 * (cap / 512)));
+      HIP_TRY(h, hipMalloc(&c.idx.bbox, sizeof(float) * 8 * (cap / 32768 + 1)));
       c.idx_cap = cap;
     }
     if (npow2 > c.keys_cap) {
@@ -468,6 +472,7 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     kd_refine_kernel<<<dim3((max_spad + kKdChunk - 1) / kKdChunk, nj), 1024, 0, lead->stream>>>(dj);
     box_tile_kernel<<<dim3((max_spad / 32 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
     box_super_kernel<<<dim3((max_spad / 512 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
+    box_block_kernel<<<dim3((max_spad / 32768 + 64) / 64, nj), 64, 0, lead->stream>>>(dj);
   }
   HIP_TRY(lead, hipGetLastError());
   for (auto& t : todo) t.second->idx_valid = true;
@@ -585,6 +590,12 @@ float gate_bound(double thr2) {
   return f;
 }
 
+void launch_pruned(dim3 grid, hipStream_t stream, const PairDesc* d_desc, float bound) {
+  static const bool v2 = std::getenv("GORIO_NN_V2") != nullptr;  // A/B switch of round 3's development (removed once measured)
+  if (v2) nn_search_pruned_v2_kernel<<<grid, 256, 0, stream>>>(d_desc, bound);
+  else nn_search_pruned_kernel<<<dim3(grid.x * (256 / kNnBlock), grid.y, grid.z), kNnBlock, 0, stream>>>(d_desc, bound);
+}
+
 void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_spad, int count, int max_tgt_n) {
   if (lead->params.search == GORIO_SEARCH_PRUNED) {
     const double thr = lead->params.corr_dist_threshold;
@@ -595,8 +606,10 @@ void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_s
     // A big, dense target has query waves that need hundreds of tiles (a far radar return whose nearest map point is a metre away
     // sits in a ball full of map points) next to waves that need two: dealing the tile groups of every wave over four workgroups
     // shortens that tail (measured on 64 scans x 1 M-point map: 2.3 -> 1.3 ms per launch; 8 and 16 are slower again).
-    if (max_tgt_n >= 131072 && splits < 4) splits = 4;
-    nn_search_pruned_kernel<<<dim3((max_src_spad + 255) / 256, splits, count), 256, 0, lead->stream>>>(d_desc, gate_bound(thr * thr));
+    if (max_tgt_n >= 131072 && splits < 8) splits = 8;  // round 3, one-wave workgroups: 4 -> 8 (20.7 -> 17.8 ms per 20 launches; 16: 20.8)
+    while (splits & (splits - 1)) splits &= splits - 1;  // the kernel deals groups by their low bits: a power of two
+    if (const char* e = std::getenv("GORIO_NN_SPLITS")) splits = std::max(1, std::min(16, std::atoi(e)));  // development: 1, 2, 4, 8, 16
+    launch_pruned(dim3((max_src_spad + 255) / 256, splits, count), lead->stream, d_desc, gate_bound(thr * thr));
   } else {
     nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(d_desc);
   }
@@ -617,6 +630,7 @@ void fill_desc(gorio_apd* h, PairDesc& d, PairState* state, long total_src_waves
   d.src = h->src->view();
   d.tgt = h->tgt->view();
   d.best_key = h->best_key;
+  d.seed = h->seed;
   d.corr = h->corr;
   d.sqd = h->sqd;
   d.omega6 = h->omega6;
@@ -914,7 +928,7 @@ void gorio_apd_destroy(gorio_apd_t* h) {
   hipFree(h->d_sub_in); hipFree(h->d_sub_out); hipFree(h->d_sub_vox); hipFree(h->d_sub_keys); hipFree(h->d_sub_counts); hipFree(h->d_sub_frames); hipFree(h->d_sub_bb); hipFree(h->d_sub_job);
   h->src.reset();
   h->tgt.reset();
-  hipFree(h->best_key); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
+  hipFree(h->best_key); hipFree(h->seed); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
   hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_ijobs); hipFree(h->d_fit); hipFree(h->d_copy_jobs);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
   delete h;
@@ -1446,7 +1460,8 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
     const int waves = (h->src->n + 63) / 64;
     int splits = 4096 / (waves > 0 ? waves : 1);
     splits = std::min(16, std::max(1, splits));
-    nn_search_pruned_kernel<<<dim3((roundup(h->src->n, 512) + 255) / 256, splits, 1), 256, 0, h->stream>>>(h->d_desc, bf);
+    while (splits & (splits - 1)) splits &= splits - 1;
+    launch_pruned(dim3((roundup(h->src->n, 512) + 255) / 256, splits, 1), h->stream, h->d_desc, bf);
   } else {
     nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
   }
@@ -2060,11 +2075,16 @@ int gorio_prep_ego_velocity(int device, const float* xyz, const float* intensity
 }  // extern "C"
 
 #ifdef GORIO_STATS
-extern "C" int gorio_debug_search_stats(unsigned long long out[8], int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gorio::g_search_stats), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+extern "C" int gorio_debug_search_stats(unsigned long long out[24], int reset) {
+  static std::vector<unsigned long long> all(1024 * 24);
+  if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(gorio::g_search_stats), sizeof(unsigned long long) * 1024 * 24) != hipSuccess) return -1;
+  for (int k = 0; k < 24; ++k) {
+    out[k] = 0;
+    for (int r = 0; r < 1024; ++r) out[k] = (k == 2 && false) ? std::max(out[k], all[(size_t)r * 24 + k]) : out[k] + all[(size_t)r * 24 + k];
+  }
   if (reset) {
-    unsigned long long z[8] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(gorio::g_search_stats), z, sizeof z) != hipSuccess) return -1;
+    std::fill(all.begin(), all.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gorio::g_search_stats), all.data(), sizeof(unsigned long long) * 1024 * 24) != hipSuccess) return -1;
   }
   return 0;
 }

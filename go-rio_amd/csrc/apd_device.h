@@ -23,8 +23,10 @@ struct SearchIndex {
   float* sy;
   float* sz;
   int* orig;     // [n_spad] original index, 0x7fffffff for padding
+  float4* s4;    // [n_spad] the same once more as (x, y, z, original index bits): ONE 16-byte load where a kernel stages a tile or reads a query
   float* tbox;   // [n_tiles][8]  lo.x lo.y lo.z - hi.x hi.y hi.z -   (tile = 32 consecutive sorted points; empty: lo = +inf, hi = -inf)
   float* sbox;   // [n_super][8]  (super tile = 16 tiles = 512 points)
+  float* bbox;   // [ceil(n_super / 64)][8]  (block = 64 super tiles = 32 768 points)
   int n;
   int n_spad;    // multiple of 512
   int n_tiles;
@@ -81,6 +83,8 @@ struct PairDesc {
   float* sqd;
   double* omega6;
   double* partials;  // [nblk][28]
+  int* seed;         // [src n_spad] by SORTED source position: original target index of the last search's winner (warm start of the next
+                     // pruned search of the same align); read only when state->n_linearize > 0, any in-range value is valid
   PairState* state;
   int nblk;          // ceil(src.n / 256)
   int nn_splits;     // target range split count for nn_search_kernel

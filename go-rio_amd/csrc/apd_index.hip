@@ -180,11 +180,13 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const IndexJob* __re
     jb.idx.sy[p] = jb.y[i];
     jb.idx.sz[p] = jb.z[i];
     jb.idx.orig[p] = i;
+    jb.idx.s4[p] = make_float4(jb.x[i], jb.y[i], jb.z[i], __int_as_float(i));
   } else {
     jb.idx.sx[p] = 1e30f;
     jb.idx.sy[p] = 1e30f;
     jb.idx.sz[p] = 1e30f;
     jb.idx.orig[p] = 0x7fffffff;
+    jb.idx.s4[p] = make_float4(1e30f, 1e30f, 1e30f, __int_as_float(0x7fffffff));
   }
 }
 
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restr
       jb.idx.sy[p] = py[e];
       jb.idx.sz[p] = pz[e];
       jb.idx.orig[p] = po[e];
+      jb.idx.s4[p] = make_float4(px[e], py[e], pz[e], __int_as_float(po[e]));
     }
   }
 }
@@ -356,6 +359,28 @@ __global__ __launch_bounds__(256) void box_super_kernel(const IndexJob* __restri
     }
   }
   float* b = jb.idx.sbox + (size_t)s * 8;
+  b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = 0.f;
+  b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = 0.f;
+}
+
+// boxes of blocks (64 super tiles), one thread per block -- grid: (blocks over n_blk, jobs)
+__global__ __launch_bounds__(64) void box_block_kernel(const IndexJob* __restrict__ jobs) {
+  const IndexJob& jb = jobs[blockIdx.y];
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= (jb.idx.n_super + 63) / 64) return;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int q = 0; q < 64; ++q) {
+    const int t = k * 64 + q;
+    if (t < jb.idx.n_super) {
+      const float* b = jb.idx.sbox + (size_t)t * 8;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = fminf(lo[a], b[a]);
+        hi[a] = fmaxf(hi[a], b[4 + a]);
+      }
+    }
+  }
+  float* b = jb.idx.bbox + (size_t)k * 8;
   b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = 0.f;
   b[4] = hi[0]; b[5] = hi[1]; b[6] = hi[2]; b[7] = 0.f;
 }
@@ -409,12 +434,24 @@ __device__ __forceinline__ float lane_f(float v, int lane) { return __uint_as_fl
 // visit order: 64-tile groups outward from `g0` (where near neighbours are expected) so the bound tightens early.
 
 #ifdef GORIO_STATS  // development statistics (never in the shipped build): work counters of the pruned searches
-__device__ unsigned long long g_search_stats[8];
-#define STAT_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_search_stats[k], (unsigned long long)(v)); } while (0)
-#define STAT_MAX(k, v) do { if ((threadIdx.x & 63) == 0) atomicMax(&g_search_stats[k], (unsigned long long)(v)); } while (0)
+// [0..7] work counters, [8..15] cycles per phase of nn_search_pruned_kernel (s_memtime), summed over waves; 1024 copies (a wave adds to the
+// copy of its number mod 1024: one shared set made the atomics the bottleneck of the instrumented kernel), summed by the host
+__device__ unsigned long long g_search_stats[1024][24];
+#define STAT_ROW() g_search_stats[((blockIdx.x + 977u * blockIdx.z) * 4u + (threadIdx.x >> 6)) & 1023u]
+#define STAT_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&STAT_ROW()[k], (unsigned long long)(v)); } while (0)
+#define STAT_MAX(k, v) do { if ((threadIdx.x & 63) == 0) atomicMax(&STAT_ROW()[k], (unsigned long long)(v)); } while (0)
 #define STAT_DECL(name) int name = 0
 #define STAT_INC(name) ++name
+// wave-local counters and phase clocks of nn_search_pruned_kernel: accumulated in registers, ONE set of atomics per wave at the end
+#define STAT_CLOCK_DECL() unsigned long long st_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned int st_cnt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t_ = __builtin_amdgcn_s_memtime()
+#define STAT_PHASE(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc_[k] += now_ - st_t_; st_t_ = now_; } while (0)
+#define STAT_LOCAL(k, v) st_cnt_[k] += (unsigned int)(v)
+#define STAT_CLOCK_FLUSH() do { if ((threadIdx.x & 63) == 0) { unsigned long long tot_ = 0; for (int k_ = 0; k_ < 8; ++k_) { tot_ += st_acc_[k_]; atomicAdd(&STAT_ROW()[8 + k_], st_acc_[k_]); atomicAdd(&STAT_ROW()[k_], (unsigned long long)st_cnt_[k_]); } int b_ = 0; while (b_ < 7 && tot_ >= (32768ull << b_)) ++b_; atomicAdd(&STAT_ROW()[16 + b_], 1ull); } } while (0)  /* [16..23]: histogram of a wave's cycles: < 32 k, < 64 k, ... */
 #else
+#define STAT_LOCAL(k, v) do { } while (0)
+#define STAT_CLOCK_DECL() do { } while (0)
+#define STAT_PHASE(k) do { } while (0)
+#define STAT_CLOCK_FLUSH() do { } while (0)
 #define STAT_ADD(k, v) do { } while (0)
 #define STAT_MAX(k, v) do { } while (0)
 #define STAT_DECL(name) do { } while (0)
@@ -424,7 +461,7 @@ __device__ unsigned long long g_search_stats[8];
 // 1-NN of every source point in the target, pruned.  One lane = one source point taken in MORTON order (a wave's 64 queries are
 // spatially compact).  grid: (ceil(n_spad_src / 256), splits, pairs), block 256.
 // Output: best_key[orig source index] = (float bits of d) << 32 | orig target index, exactly as nn_search_kernel.
-__global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* __restrict__ descs, float bound_f) {
+__global__ __launch_bounds__(256) void nn_search_pruned_v2_kernel(const PairDesc* __restrict__ descs, float bound_f) {
   const PairDesc& pd = descs[blockIdx.z];
   const PairState* __restrict__ st = pd.state;
   if (st->done) return;
@@ -609,6 +646,452 @@ __global__ __launch_bounds__(256) void nn_search_pruned_kernel(const PairDesc* _
     if (nsplit > 1) atomicMin(pd.best_key + si.orig[p], best);
     else pd.best_key[si.orig[p]] = best;
   }
+}
+
+// ----------------------------------------------------------------------------------------------- 1-NN, round 3 form
+//
+// Same answer, same tile tests; what changed is WHERE the instructions go (the round-2 kernel filled 52 % of the VALU issue time alone,
+// 61 % of it with half-rate instructions):
+//   * wave reductions by DPP (v_max_u32 row_ror / row_bcast on order-preserving integer keys) instead of six ds_bpermute round trips each;
+//     the results are wave-uniform SGPR values.
+//   * the box of a candidate tile arrives by a scalar load (s_load_dwordx8, prefetched one candidate ahead) instead of six v_readlane, and
+//     its per-lane lower bound is max3(lo - q, q - hi, 0) per axis: 11 full-rate + 4 half-rate instructions (was 8 + 12 + 6 readlanes).
+//   * the (lane, tile) evaluations of a batch are COMPACTED: the round-2 walk took max-over-lanes rounds per batch (4.7 rounds of 64
+//     lanes per wave for 2.2 tiles per lane); now every (query, slot) pair becomes an item of a list in LDS and the wave evaluates
+//     64 items per round whatever query they belong to (the query is re-read from LDS).
+//   * an item keeps only the MINIMUM distance of its 32 candidates (v_min3_u32 on the float bits: 0.56 half-rate instruction per
+//     candidate instead of a 64-bit compare and two selects) and which 8-candidate groups hold it; items meet in an LDS atomic
+//     min on (distance bits, slot, groups); the owning lane then re-evaluates only the winning group to recover the ORIGINAL index
+//     (lowest index among equal distances).  Equal minima from two different tiles -- the only case the packed key cannot order by
+//     index -- raise a flag and that lane re-walks its slots with full (distance, index) keys.
+//   * the previous correspondence (by sorted source position, pd.seed) seeds only the BOUND; its index is found again when its tile
+//     is evaluated (the tile's box bound never exceeds the distance of a point inside it, so the tile is always taken).
+//   * tiles are staged from one float4 array (x, y, z, original index) of the index: one 16-byte load per point instead of four.
+#ifndef GORIO_NN_SLOTS
+#define GORIO_NN_SLOTS 8
+#endif
+#ifndef GORIO_NN_WAVES
+#define GORIO_NN_WAVES 5
+#endif
+#ifndef GORIO_NN_BLOCK
+#define GORIO_NN_BLOCK 64  // threads per workgroup: the waves of a workgroup never cooperate, and a workgroup holds its LDS until its SLOWEST wave ends
+#endif
+constexpr int kNnBlock = GORIO_NN_BLOCK;
+
+// wave-wide max / min of an unsigned key by DPP; the result is wave-uniform (an SGPR after readlane)
+__device__ __forceinline__ unsigned int wave_umax(unsigned int v) {
+  int x = (int)v;
+#define GORIO_DPP_MAX(ctrl, rmask) x = (int)max((unsigned int)x, (unsigned int)__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, true))
+  GORIO_DPP_MAX(0x128, 0xf);  // row_ror:8
+  GORIO_DPP_MAX(0x124, 0xf);  // row_ror:4
+  GORIO_DPP_MAX(0x122, 0xf);  // row_ror:2
+  GORIO_DPP_MAX(0x121, 0xf);  // row_ror:1  -> every lane holds its row's maximum
+  GORIO_DPP_MAX(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  GORIO_DPP_MAX(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef GORIO_DPP_MAX
+  return (unsigned int)__builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ float wave_fmax_u(float v) { return ord2f(wave_umax(f2ord(v))); }
+__device__ __forceinline__ float wave_fmin_u(float v) { return ord2f(~wave_umax(~f2ord(v))); }
+
+__device__ __forceinline__ unsigned int umin3(unsigned int a, unsigned int b, unsigned int c) { return min(min(a, b), c); }
+
+struct TileBox {
+  float lx, ly, lz, p0, hx, hy, hz, p1;
+};
+__device__ __forceinline__ TileBox sload_box(scalar_fp tb, int tile) {  // tile is wave-uniform: one s_load_dwordx8
+  const scalar_fp b = tb + (size_t)tile * 8;
+  TileBox r;
+  r.lx = b[0]; r.ly = b[1]; r.lz = b[2]; r.p0 = b[3]; r.hx = b[4]; r.hy = b[5]; r.hz = b[6]; r.p1 = b[7];
+  return r;
+}
+// per-lane lower bound of sqdist3(q, p) over the box: per axis max(lo - q, q - hi, 0) is |q - clamp(q)| computed without a clamp, and
+// the squares are summed in the order of sqdist3, so the value is the one box_bound() gives
+__device__ __forceinline__ float box_bound_s(float qx, float qy, float qz, const TileBox& b) {
+  const float dx = fmaxf(fmaxf(b.lx - qx, qx - b.hx), 0.0f);
+  const float dy = fmaxf(fmaxf(b.ly - qy, qy - b.hy), 0.0f);
+  const float dz = fmaxf(fmaxf(b.lz - qz, qz - b.hz), 0.0f);
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+// grid: (ceil(n_spad_src / kNnBlock), splits, pairs), block kNnBlock.  Output as nn_search_kernel: best_key[orig source index].
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+struct global_f4p {  // 16-byte loads through the GLOBAL address space (descriptor members are generic pointers: a plain load would be flat_load)
+  const __attribute__((address_space(1))) v4f_t* p;
+  __device__ __forceinline__ explicit global_f4p(const void* q) : p((const __attribute__((address_space(1))) v4f_t*)q) {}
+  __device__ __forceinline__ float4 operator[](size_t i) const {
+    const v4f_t v = p[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+};
+// LDS byte address of a __shared__ object and eight 16-byte LDS reads issued back to back with ONE wait.  Written as one asm block
+// because the compiler (i) narrows a float4 read whose .w is unused to ds_read_b96, which takes 8 LDS cycles instead of 4, and
+// (ii) hoists every read of an unrolled loop to its top, which costs a wave per SIMD in registers here.
+__device__ __forceinline__ unsigned int lds_addr(const void* p) { return (unsigned int)(size_t)(const __attribute__((address_space(3))) char*)p; }
+__device__ __forceinline__ void lds_read8_b128(v4f_t (&c)[8], unsigned int addr) {
+  asm volatile(
+      "ds_read_b128 %0, %8\n\t"
+      "ds_read_b128 %1, %8 offset:16\n\t"
+      "ds_read_b128 %2, %8 offset:32\n\t"
+      "ds_read_b128 %3, %8 offset:48\n\t"
+      "ds_read_b128 %4, %8 offset:64\n\t"
+      "ds_read_b128 %5, %8 offset:80\n\t"
+      "ds_read_b128 %6, %8 offset:96\n\t"
+      "ds_read_b128 %7, %8 offset:112\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+      : "v"(addr)
+      : "memory");
+}
+
+__global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_NN_WAVES, GORIO_NN_WAVES))) void nn_search_pruned_kernel(const PairDesc* __restrict__ descs, float bound_f) {
+  const PairDesc& pd = descs[blockIdx.z];
+  // the optimiser state is constant while this kernel runs: read it through the scalar cache (a generic pointer would make these flat
+  // loads, whose completion the compiler can only wait for together with every other outstanding load)
+  const __attribute__((address_space(4))) PairState* st = (const __attribute__((address_space(4))) PairState*)pd.state;
+  if (st->done) return;
+  const SearchIndex& si = pd.src.idx;
+  const SearchIndex& ti = pd.tgt.idx;
+  const int p = blockIdx.x * kNnBlock + threadIdx.x;
+  if (blockIdx.x * kNnBlock >= si.n) return;
+  if ((int)(blockIdx.x * kNnBlock) < pd.shard_lo || (int)(blockIdx.x * kNnBlock) >= pd.shard_hi) return;  // another rank's part of the source (bounds are multiples of 256)
+  constexpr int S = GORIO_NN_SLOTS;
+  constexpr unsigned int kNone = 0xffffffffu;
+  static_assert(S >= 2 && S <= 16, "slot index is packed into 4 bits");
+  __shared__ float4 s_pts[kNnBlock / 64][S][33];  // 33: slots 528 B apart -> lanes on different slots hit different banks
+  __shared__ float4 s_q[kNnBlock / 64][64];
+  __shared__ unsigned long long s_win[kNnBlock / 64][64];
+  __shared__ unsigned short s_items[kNnBlock / 64][64 * S];
+  __shared__ unsigned long long s_tie[kNnBlock / 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  STAT_CLOCK_DECL();
+  const int pq = p < si.n ? p : si.n - 1;
+  const global_f4p tb4(ti.tbox);
+  const global_f4p sb4(ti.sbox);
+  const global_f4p kb4(ti.bbox);
+  const global_f4p t4(ti.s4);
+  const int ng = (ti.n_tiles + 63) / 64;
+  const int n_blk = (ti.n_super + 63) >> 6;  // block = 64 super tiles = 16 groups = 32 768 points
+  int g0 = (int)(((long)(blockIdx.x * kNnBlock + (threadIdx.x & ~63)) * ng) / (si.n > 0 ? si.n : 1));
+  g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);
+  // ---- every load that does not depend on the bound is issued NOW, ahead of the seed chain (the kernel is a chain of dependent
+  // round trips to L2, 1-2 k cycles each under load): the query, its seed, the boxes of the first 64 blocks, of the super tiles of the
+  // home block and of the tiles of the home group (where the wave's queries sit in the target's order: almost always the first group
+  // visited).  The traversal below takes a box from these registers when the id matches and loads it otherwise.
+  const float4 kInfLo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), kInfHi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+  // (every index is clamped into its array and the condition applied to the loaded value: a load inside a branch ends the compiler's
+  // tracking of outstanding loads at the join, and it then waits for ALL of them at the first use of any)
+  // the seed first: the point it names is the one dependent load of this block, and the counter of outstanding loads is in order
+  int sd = ((const __attribute__((address_space(1))) int*)pd.seed)[pq];  // garbage before the first search of an align: used only when seeded
+  __builtin_amdgcn_sched_barrier(0);
+  const float4 sp = global_f4p(si.s4)[pq];
+  const bool seeded = st->n_linearize > 0;
+  int pt_g = g0;  // group whose tile boxes sit in (pt_lo, pt_hi)
+  float4 pt_lo, pt_hi;
+  {
+    const int t = g0 * 64 + lane, tc = t < ti.n_tiles ? t : ti.n_tiles - 1;
+    pt_lo = tb4[2 * (size_t)tc];  // lanes past the last tile hold a copy of it: they are masked out of the ballot, not out of the data
+    pt_hi = tb4[2 * (size_t)tc + 1];
+  }
+  const int ps_b = g0 >> 4;  // block whose super-tile boxes sit in (ps_lo, ps_hi)
+  float4 ps_lo, ps_hi;
+  {
+    const int t = ps_b * 64 + lane, tc = t < ti.n_super ? t : ti.n_super - 1;
+    ps_lo = sb4[2 * (size_t)tc];
+    ps_hi = sb4[2 * (size_t)tc + 1];
+  }
+  float4 pk_lo, pk_hi;  // boxes of blocks 0 .. 63
+  {
+    const int tc = lane < n_blk ? lane : n_blk - 1;
+    pk_lo = kb4[2 * (size_t)tc];
+    pk_hi = kb4[2 * (size_t)tc + 1];
+  }
+  if (!seeded || p >= si.n || sd < 0 || sd >= pd.tgt.n) sd = -1;
+  const float4 tp = global_f4p(pd.tgt.p4)[sd < 0 ? 0 : sd];
+  float qx, qy, qz;
+  {
+    float Tf[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Tf[i] = st->Tf[i];
+    transform_f(Tf, sp.x, sp.y, sp.z, qx, qy, qz);
+  }
+  // candidates farther than the correspondence gate can never be accepted (APD:183): the gate is the first bound.  Warm start inside one
+  // align: the correspondence of the previous linearisation, evaluated under the CURRENT pose with the same expression as any other
+  // candidate, tightens the bound; the answer does not depend on it (any target point is a valid seed).
+  float bestd = bound_f;
+  {
+    const float d = sqdist3(qx, qy, qz, tp.x, tp.y, tp.z);
+    if (sd >= 0 && d <= bestd) bestd = d;
+  }
+  unsigned long long best = ((unsigned long long)__float_as_uint(bestd) << 32) | kNone;  // index unknown until a tile delivers it
+  s_q[wave][lane] = make_float4(qx, qy, qz, 0.f);
+  const float qlo[3] = {wave_fmin_u(qx), wave_fmin_u(qy), wave_fmin_u(qz)};
+  const float qhi[3] = {wave_fmax_u(qx), wave_fmax_u(qy), wave_fmax_u(qz)};
+  float wb = __uint_as_float(wave_umax(__float_as_uint(bestd)));  // loosest bound of the wave (distances are >= 0: the bits order like the values)
+  STAT_LOCAL(5, 1);
+  // workgroups of one query wave (gridDim.y > 1 only when a launch has too few query waves to fill the chip, or for big targets) share the
+  // groups round-robin: bit pattern of "my" groups inside any 64-group word (gridDim.y is a power of two <= 16)
+  const int nsplit = gridDim.y;
+  unsigned long long mine = 1ull << (blockIdx.y & 63);
+  for (int sft = nsplit; sft < 64; sft <<= 1) mine |= mine << sft;
+  // The first, unseeded launch of an align has only the gate as its bound: it flushes its first batch after two tiles so that every lane
+  // owns a real bound before the remaining tiles are tested.
+  int flush_at = seeded ? S : 2;
+  unsigned int mneed = 0u;  // slots of the current batch this lane must visit
+  int slot_tile = 0;        // lane s: tile held by slot s
+  int nslots = 0;           // wave-uniform
+  // The traversal is ONE loop over a wave-uniform state (so the batch evaluation below exists once in the code).  FOUR levels of boxes:
+  // blocks (32 768 points) 64 per instruction against the box of the wave's queries and its loosest bound; the 64 super tiles (512 points,
+  // four per group of 64 tiles) of every surviving block -> bit mask of the groups that can matter at all (a pass covers 2048 groups; the
+  // words of the mask live in lane w of a register pair); those groups, nearest (in index order, which follows space) first, get the
+  // tile-level test one tile per lane, the next group's boxes being loaded while this group's tiles are tested; the surviving tiles are
+  // tested per lane against boxes broadcast with v_readlane.
+  constexpr int kPassGroups = 2048;
+  int c0 = -kPassGroups, cg = 0, nwords = 0, gl = 0, w0 = 0, v = 0, wcur = 0, pivot = 0, g = 0;
+  unsigned long long gm = 0ull, mask = 0ull;
+  unsigned int gmw_lo = 0u, gmw_hi = 0u;  // lane w: word w of the pass's group mask
+  float4 lo = pt_lo, hi = pt_hi;          // tile boxes of the current group, one tile per lane
+  bool done = false;
+  auto nearest_bit = [](unsigned long long m, int pv) -> int {  // the set bit nearest to pv (ties: upward)
+    const unsigned long long up = m & (~0ull << pv), dn = m & ~(~0ull << pv);
+    const int bu = up ? __builtin_ctzll(up) : 1000, bd = dn ? 63 - __builtin_clzll(dn) : -1000;
+    return (bu - pv) <= (pv - bd) ? bu : bd;
+  };
+  STAT_PHASE(0);
+  for (;;) {
+    while (!mask && !done) {  // advance to the next group that has candidate tiles
+      if (gm) {
+        // groups are visited outward from where the queries sit, so the bound tightens early
+        const int bit = nearest_bit(gm, pivot);
+        gm &= ~(1ull << bit);
+        g = c0 + wcur * 64 + bit;
+        if (pt_g == g) {
+          lo = pt_lo;
+          hi = pt_hi;
+        } else {
+          const int t = g * 64 + lane, tc = t < ti.n_tiles ? t : ti.n_tiles - 1;
+          lo = tb4[2 * (size_t)tc];
+          hi = tb4[2 * (size_t)tc + 1];
+        }
+        mask = __ballot(g * 64 + lane < ti.n_tiles && box_box_bound(qlo, qhi, lo, hi) <= wb);
+        if (gm) {  // the boxes of the group that will be visited next are in flight while this group's tiles are tested and evaluated (issued
+                   // AFTER the last use of this group's loads, so that no wait for those covers these)
+          pt_g = c0 + wcur * 64 + nearest_bit(gm, pivot);
+          const int t = pt_g * 64 + lane, tc = t < ti.n_tiles ? t : ti.n_tiles - 1;
+          pt_lo = tb4[2 * (size_t)tc];
+          pt_hi = tb4[2 * (size_t)tc + 1];
+        }
+        STAT_LOCAL(7, __builtin_popcountll(mask));
+        STAT_LOCAL(1, 1);
+        continue;
+      }
+      if (v < 2 * nwords) {
+        const int woff = (v + 1) >> 1;
+        wcur = (v & 1) ? w0 - woff : w0 + woff;
+        ++v;
+        if (wcur < 0 || wcur >= nwords) continue;
+        gm = (((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)gmw_hi, wcur) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)gmw_lo, wcur)) & mine;
+        pivot = wcur == w0 ? (gl & 63) : (wcur > w0 ? 0 : 63);
+        continue;
+      }
+      c0 += kPassGroups;  // next pass of up to 2048 groups = 128 blocks
+      if (c0 >= ng) {
+        done = true;
+        break;
+      }
+      cg = ng - c0 < kPassGroups ? ng - c0 : kPassGroups;
+      nwords = (cg + 63) >> 6;
+      gmw_lo = 0u;
+      gmw_hi = 0u;
+      for (int bw = 0; bw < 2; ++bw) {  // the pass's blocks, 64 per ballot
+        const int blk_base = (c0 >> 4) + bw * 64;
+        if (blk_base >= n_blk) break;
+        unsigned long long bm = 1ull;  // a target of one block: nothing to test
+        if (n_blk > 1) {
+          float4 klo = pk_lo, khi = pk_hi;
+          if (blk_base != 0) {
+            const int tc = blk_base + lane < n_blk ? blk_base + lane : n_blk - 1;
+            klo = kb4[2 * (size_t)tc];
+            khi = kb4[2 * (size_t)tc + 1];
+          }
+          bm = __ballot(blk_base + lane < n_blk && box_box_bound(qlo, qhi, klo, khi) <= wb);
+        }
+        STAT_LOCAL(2, __builtin_popcountll(bm));
+        while (bm) {
+          const int bb = __builtin_ctzll(bm);
+          bm &= bm - 1;
+          const int blk = blk_base + bb;
+          float4 slo = ps_lo, shi = ps_hi;
+          if (ps_b != blk) {
+            const int t = blk * 64 + lane, tc = t < ti.n_super ? t : ti.n_super - 1;
+            slo = sb4[2 * (size_t)tc];
+            shi = sb4[2 * (size_t)tc + 1];
+          }
+          unsigned long long m = __ballot(blk * 64 + lane < ti.n_super && box_box_bound(qlo, qhi, slo, shi) <= wb);
+          m |= m >> 1;
+          m |= m >> 2;  // bit 4 j: any of the four super tiles of group j
+          m &= 0x1111111111111111ull;
+          m = (m | (m >> 3)) & 0x0303030303030303ull;
+          m = (m | (m >> 6)) & 0x000f000f000f000full;
+          m = (m | (m >> 12)) & 0x000000ff000000ffull;
+          m = (m | (m >> 24)) & 0xffffull;  // 16 group bits of this block
+          const int rel = blk - (c0 >> 4);  // block inside the pass: word rel / 4, bits (rel % 4) * 16 ..
+          const unsigned long long sh = m << ((rel & 3) * 16);
+          if (lane == (rel >> 2)) {
+            gmw_lo |= (unsigned int)sh;
+            gmw_hi |= (unsigned int)(sh >> 32);
+          }
+        }
+      }
+      gl = g0 - c0;  // where near neighbours are expected, relative to this pass
+      gl = gl < 0 ? 0 : (gl >= cg ? cg - 1 : gl);
+      w0 = gl >> 6;
+      v = 0;
+    }
+    STAT_PHASE(1);
+    if (mask) {  // one candidate tile: its box is broadcast from the lane that holds it
+      const int cur = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float bx0 = lane_f(lo.x, cur), bx1 = lane_f(lo.y, cur), bx2 = lane_f(lo.z, cur);
+      const float bx4 = lane_f(hi.x, cur), bx5 = lane_f(hi.y, cur), bx6 = lane_f(hi.z, cur);
+      const TileBox bcur = TileBox{bx0, bx1, bx2, 0.f, bx4, bx5, bx6, 0.f};
+      const bool need = box_bound_s(qx, qy, qz, bcur) <= bestd;
+      if (__ballot(need)) {
+        if (need) mneed |= 1u << nslots;
+        if (lane == nslots) slot_tile = g * 64 + cur;
+        ++nslots;
+        STAT_LOCAL(0, 1);
+      }
+    }
+    STAT_PHASE(2);
+    if (nslots >= flush_at || (done && nslots > 0)) {
+      flush_at = S;
+      // ---- batch evaluation
+      // 1. stage the tiles: lanes 0-31 / 32-63 bring one point each of two slots per pass; all loads are issued before the first store
+      //    (slots beyond nslots re-load an older tile and are not stored)
+      float4 stage[(S + 1) / 2];
+#pragma unroll
+      for (int h = 0; h < (S + 1) / 2; ++h) {
+        const int ta = __builtin_amdgcn_readlane(slot_tile, 2 * h);
+        const int tb = __builtin_amdgcn_readlane(slot_tile, 2 * h + 1 < S ? 2 * h + 1 : 2 * h);
+        const int tile = lane < 32 ? ta : tb;
+        stage[h] = t4[(size_t)tile * 32 + (lane & 31)];
+      }
+#pragma unroll
+      for (int h = 0; h < (S + 1) / 2; ++h) {
+        const int my = 2 * h + (lane >> 5);
+        if (my < nslots) s_pts[wave][my][lane & 31] = stage[h];
+      }
+      STAT_PHASE(3);
+      // 2. item list, slot-major (consecutive items mostly share a slot: their candidate reads are LDS broadcasts)
+      int nitems = 0;
+      for (int s = 0; s < nslots; ++s) {
+        const bool mine = (mneed >> s) & 1u;
+        const unsigned long long bal = __ballot(mine);
+        if (mine) s_items[wave][nitems + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0u))] = (unsigned short)((lane << 4) | s);
+        nitems += __builtin_popcountll(bal);
+      }
+      s_win[wave][lane] = ((unsigned long long)__float_as_uint(bestd) << 32) | kNone;
+      if (lane == 0) s_tie[wave] = 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      STAT_LOCAL(3, nitems);
+      STAT_LOCAL(6, 1);
+      STAT_PHASE(4);
+      // 3. rounds of 64 items: minimum of the tile's 32 distances (float bits, v_min3_u32) and the 8-candidate groups that hold it
+      for (int r0 = 0; r0 < nitems; r0 += 64) {
+        STAT_LOCAL(4, 1);
+        const int i = r0 + lane;
+        const bool valid = i < nitems;
+        const unsigned int it = valid ? (unsigned int)s_items[wave][i] : 0u;
+        const int Q = (int)(it >> 4), sl = (int)(it & 15u);
+        const float4 q4 = s_q[wave][Q];
+        unsigned int mg[4];
+        const unsigned int cp_addr = lds_addr(&s_pts[wave][sl][0]);
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          v4f_t c[8];
+          lds_read8_b128(c, cp_addr + gg * 128);  // eight 16-byte reads in flight, one wait (the compiler would hoist all 32: 128 registers)
+          unsigned int d[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) d[k] = __float_as_uint(sqdist3(q4.x, q4.y, q4.z, c[k].x, c[k].y, c[k].z));
+          mg[gg] = umin3(umin3(d[0], d[1], d[2]), umin3(d[3], d[4], d[5]), min(d[6], d[7]));
+          asm volatile("" : "+v"(mg[gg]));  // pins this group's arithmetic between its reads and the next group's (volatile asm keeps its order)
+        }
+        const unsigned int m = min(umin3(mg[0], mg[1], mg[2]), mg[3]);
+        const unsigned int gmk = (mg[0] == m ? 1u : 0u) | (mg[1] == m ? 2u : 0u) | (mg[2] == m ? 4u : 0u) | (mg[3] == m ? 8u : 0u);
+        if (valid) {
+          const unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)(((unsigned int)sl << 4) | gmk);
+          const unsigned long long old = atomicMin(&s_win[wave][Q], key);
+          // equal minima in two tiles: the packed key cannot say which holds the lower original index
+          if ((unsigned int)(old >> 32) == m && (unsigned int)old != kNone) atomicOr(&s_tie[wave], 1ull << Q);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      STAT_PHASE(5);
+      // 4. the owner of a query recovers the original index of its winner from the winning group(s)
+      const unsigned long long w = s_win[wave][lane];
+      const unsigned long long ties = s_tie[wave];
+      if ((unsigned int)w != kNone) {
+        const unsigned int m = (unsigned int)(w >> 32);
+        const int sl = (int)(((unsigned int)w >> 4) & 15u);
+        unsigned int gmk = (unsigned int)w & 15u;
+        unsigned int idx = kNone;
+        const float4* __restrict__ cp = s_pts[wave][sl];
+        while (gmk) {
+          const int gg = __builtin_ctz(gmk);
+          gmk &= gmk - 1u;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float4 c = cp[gg * 8 + k];
+            const unsigned int d = __float_as_uint(sqdist3(qx, qy, qz, c.x, c.y, c.z));
+            const unsigned int ci = __float_as_uint(c.w);
+            idx = d == m ? min(idx, ci) : idx;
+          }
+        }
+        const unsigned long long key = ((unsigned long long)m << 32) | (unsigned long long)idx;
+        best = key < best ? key : best;
+      }
+      if (ties) {  // rare: lanes whose minimum occurred in more than one tile walk all their slots with full keys
+        if ((ties >> lane) & 1ull) {
+          unsigned int mm = mneed;
+          while (mm) {
+            const int sl = __builtin_ctz(mm);
+            mm &= mm - 1u;
+#pragma unroll 1
+            for (int k = 0; k < 32; ++k) {
+              const float4 c = s_pts[wave][sl][k];
+              const float d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
+              const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(c.w);
+              best = key < best ? key : best;
+            }
+          }
+        }
+      }
+      bestd = __uint_as_float((unsigned int)(best >> 32));
+      wb = __uint_as_float(wave_umax(__float_as_uint(bestd)));
+      nslots = 0;
+      mneed = 0u;
+      __builtin_amdgcn_wave_barrier();
+      STAT_PHASE(6);
+    }
+    if (done) break;
+  }
+  if (p < si.n && (unsigned int)best != kNone) {
+    const int oi = __float_as_int(sp.w);  // original index of this query (the .w of its sorted record)
+    if (nsplit > 1) atomicMin(pd.best_key + oi, best);
+    else pd.best_key[oi] = best;
+    pd.seed[p] = (int)(unsigned int)best;  // next launch's warm start (with nsplit > 1 whichever workgroup writes last: any target point is valid)
+  }
+  STAT_PHASE(7);
+  STAT_CLOCK_FLUSH();
 }
 
 // Insertion of a packed key ((float bits of d) << 32 | original index; d >= 0, so the integer order IS the lexicographic

@@ -30,7 +30,7 @@ for q in range(n_pairs):
     objs.append(o)
     guesses.append(pose.astype(np.float32))
 guesses = np.stack(guesses)
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 24)()
 names = ["rounds in heavy waves", "heavy waves (> 64 rounds)", "max rounds of a wave", "lane0 items", "eval rounds", "waves", "tiles needed", "tiles past coarse"]
 prev = None
 for it in (1, 2, 3, 6, 10):

@@ -1,0 +1,24 @@
+set -x
+mkdir -p gpurun_out/r03
+timeout -k 10 900 python -m pytest tests/test_apd_gpu.py tests/test_configs_gpu.py tests/test_c5_gpu.py tests/test_real_clouds.py tests/test_golden.py -m gpu -x -q > gpurun_out/r03/t6.log 2>&1
+rc=$?
+tail -5 gpurun_out/r03/t6.log
+[ $rc -eq 0 ] || exit $rc
+B="--steps 10 --warmup 2 --no-overlap --no-cpu-baseline --no-exhaustive --no-check"
+for v in nn_s8w5b64 nn_s8w5b256 nn_s12w4b64 nn_s8w4b64; do
+  GORIO_AMD_LIB=$PWD/tools/variants/$v.so timeout -k 10 300 python bench.py $B > gpurun_out/r03/ab6_$v.json 2> gpurun_out/r03/ab6_$v.err || exit 1
+done
+for v in nn_s8w5b64 nn_s12w4b64; do
+ for sp in 1 2 4; do
+  GORIO_NN_SPLITS=$sp GORIO_AMD_LIB=$PWD/tools/variants/$v.so timeout -k 10 400 python bench.py --workload c5 --steps 5 --warmup 1 --no-cpu-baseline --no-exhaustive --no-check > gpurun_out/r03/c56_${v}_sp$sp.json 2> gpurun_out/r03/c56_${v}_sp$sp.err || exit 1
+ done
+done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r03/ab6_*.json')+glob.glob('gpurun_out/r03/c56_*.json')):
+    try:
+        d=json.load(open(f)); print(f, round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['device_ms_per_step'].items() if not k.startswith('ugpm')})
+    except Exception as e: print(f, 'ERR', e)
+PY
+bash tools/r03/prof_nn.sh v6_s8w5b64_c4 $PWD/tools/variants/nn_s8w5b64.so c4 > /dev/null 2>&1
+grep -h "nn_search_pruned" gpurun_out/r03/prof_v6_s8w5b64_c4/*_per_kernel.csv
