@@ -73,6 +73,9 @@ struct gorio_apd {
   // per-source-point state
   unsigned long long* best_key = nullptr;
   int* seed = nullptr;     // warm start of the pruned search, by sorted source position (PairDesc::seed)
+  unsigned int* nn_work = nullptr;  // PairDesc::nn_work / nn_plan (measured work of the query waves, plan of the next searches)
+  unsigned int* nn_plan = nullptr;
+  int nn_wcap = 0;
   int* corr = nullptr;
   float* sqd = nullptr;
   double* omega6 = nullptr;
@@ -223,11 +226,16 @@ int ensure_cloud(gorio_apd* h, DevCloud& c, int n) {
 
 int ensure_points(gorio_apd* h, int n) {
   if (n > h->pt_cap) {
-    hipFree(h->best_key); hipFree(h->seed); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
-    h->best_key = nullptr; h->seed = nullptr; h->corr = nullptr; h->sqd = nullptr; h->omega6 = nullptr; h->partials = nullptr;
+    hipFree(h->best_key); hipFree(h->seed); hipFree(h->nn_work); hipFree(h->nn_plan); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
+    h->best_key = nullptr; h->seed = nullptr; h->nn_work = nullptr; h->nn_plan = nullptr; h->corr = nullptr; h->sqd = nullptr; h->omega6 = nullptr; h->partials = nullptr;
     const int cap = n + n / 8 + 256;
     HIP_TRY(h, hipMalloc(&h->best_key, sizeof(unsigned long long) * cap));
     HIP_TRY(h, hipMalloc(&h->seed, sizeof(int) * (cap + 512)));  // indexed by sorted position < roundup(n, 512)
+    h->nn_wcap = (cap + 512) / 64 + 1;
+    HIP_TRY(h, hipMalloc(&h->nn_work, sizeof(unsigned int) * 2 * h->nn_wcap));
+    HIP_TRY(h, hipMalloc(&h->nn_plan, sizeof(unsigned int) * (1 + 2 * (size_t)h->nn_wcap)));
+    HIP_TRY(h, hipMemsetAsync(h->nn_work, 0, sizeof(unsigned int) * 2 * h->nn_wcap, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->nn_plan, 0, sizeof(unsigned int) * (1 + 2 * (size_t)h->nn_wcap), h->stream));
     HIP_TRY(h, hipMalloc(&h->corr, sizeof(int) * cap));
     HIP_TRY(h, hipMalloc(&h->sqd, sizeof(float) * cap));
     HIP_TRY(h, hipMalloc(&h->omega6, sizeof(double) * 6 * cap));
@@ -590,26 +598,34 @@ float gate_bound(double thr2) {
   return f;
 }
 
-void launch_pruned(dim3 grid, hipStream_t stream, const PairDesc* d_desc, float bound) {
-  static const bool v2 = std::getenv("GORIO_NN_V2") != nullptr;  // A/B switch of round 3's development (removed once measured)
-  if (v2) nn_search_pruned_v2_kernel<<<grid, 256, 0, stream>>>(d_desc, bound);
-  else nn_search_pruned_kernel<<<dim3(grid.x * (256 / kNnBlock), grid.y, grid.z), kNnBlock, 0, stream>>>(d_desc, bound);
+// mode: bit 0 = which half of nn_work this launch accumulates into, bit 1 = take the work list of nn_plan_kernel instead of the grid position
+void launch_pruned(dim3 grid, hipStream_t stream, const PairDesc* d_desc, float bound, int mode) {
+  nn_search_pruned_kernel<<<dim3(grid.x * (256 / kNnBlock), grid.y, grid.z), kNnBlock, 0, stream>>>(d_desc, bound, mode);
 }
 
-void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_spad, int count, int max_tgt_n) {
+// launch_index: position of this search inside its align (0 = the unseeded one), or -1 for a search outside an align loop.  From the third
+// search of an align on, the work measured in the second one (the first seeded one) decides which query waves are cut into parts and
+// which run first (nn_plan_kernel); the first two use the grid position, with the groups of every wave dealt over `splits` workgroups.
+void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_spad, int count, int max_tgt_n, int launch_index = -1) {
   if (lead->params.search == GORIO_SEARCH_PRUNED) {
     const double thr = lead->params.corr_dist_threshold;
     const long waves = (long)count * ((max_src_spad + 63) / 64);
+    static const bool no_plan = std::getenv("GORIO_NN_NO_PLAN") != nullptr;  // debug switch: every search with the natural schedule
+    const bool planned = launch_index >= 2 && !lead->comm && !lead->shard_only && !no_plan;
+    if (planned) {
+      launch_pruned(dim3(2 * ((max_src_spad + 255) / 256), 1, count), lead->stream, d_desc, gate_bound(thr * thr), 2 | (launch_index & 1));
+      return;
+    }
     int splits = (int)(4096 / (waves > 0 ? waves : 1));  // a lone 16k scan has 256 query waves: deal the tile groups over more workgroups
     if (splits < 1) splits = 1;
     if (splits > 16) splits = 16;
     // A big, dense target has query waves that need hundreds of tiles (a far radar return whose nearest map point is a metre away
-    // sits in a ball full of map points) next to waves that need two: dealing the tile groups of every wave over four workgroups
-    // shortens that tail (measured on 64 scans x 1 M-point map: 2.3 -> 1.3 ms per launch; 8 and 16 are slower again).
-    if (max_tgt_n >= 131072 && splits < 8) splits = 8;  // round 3, one-wave workgroups: 4 -> 8 (20.7 -> 17.8 ms per 20 launches; 16: 20.8)
+    // sits in a ball full of map points) next to waves that need two: dealing the tile groups of every wave over several workgroups
+    // shortens that tail until the plan takes over.
+    if (max_tgt_n >= 131072 && splits < 8) splits = 8;
     while (splits & (splits - 1)) splits &= splits - 1;  // the kernel deals groups by their low bits: a power of two
-    if (const char* e = std::getenv("GORIO_NN_SPLITS")) splits = std::max(1, std::min(16, std::atoi(e)));  // development: 1, 2, 4, 8, 16
-    launch_pruned(dim3((max_src_spad + 255) / 256, splits, count), lead->stream, d_desc, gate_bound(thr * thr));
+    launch_pruned(dim3((max_src_spad + 255) / 256, splits, count), lead->stream, d_desc, gate_bound(thr * thr), launch_index >= 0 ? (launch_index & 1) : 0);
+    if (launch_index == 1 && !lead->comm && !lead->shard_only && !no_plan) nn_plan_kernel<<<count, 256, 0, lead->stream>>>(d_desc, 1, count);
   } else {
     nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(d_desc);
   }
@@ -631,6 +647,10 @@ void fill_desc(gorio_apd* h, PairDesc& d, PairState* state, long total_src_waves
   d.tgt = h->tgt->view();
   d.best_key = h->best_key;
   d.seed = h->seed;
+  d.nn_work = h->nn_work;
+  d.nn_plan = h->nn_plan;
+  d.nn_wcap = h->nn_wcap;
+  d.pad0_ = 0;
   d.corr = h->corr;
   d.sqd = h->sqd;
   d.omega6 = h->omega6;
@@ -673,6 +693,11 @@ void init_state(PairState& s, const double* T16) {
 __global__ __launch_bounds__(256) void arm_keys_kernel(const PairDesc* __restrict__ descs) {
   const PairDesc& pd = descs[blockIdx.y];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < pd.src.n; i += gridDim.x * 256) pd.best_key[i] = ~0ull;
+  if (pd.nn_work)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < pd.nn_wcap; i += gridDim.x * 256) {
+      pd.nn_work[i] = 0u;
+      pd.nn_work[pd.nn_wcap + i] = 0u;
+    }
 }
 __global__ __launch_bounds__(64) void gather_states_kernel(const PairDesc* __restrict__ descs, PairState* __restrict__ out) {
   const unsigned int* s = reinterpret_cast<const unsigned int*>(descs[blockIdx.x].state);
@@ -825,7 +850,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     const int todo_it = std::min(chunk_iters, max_it - launched);
     StageChain chain(lead);
     for (int it = 0; it < todo_it; ++it) {
-      launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), count, max_m);
+      launch_nn(lead, lead->d_desc, g_nn, roundup(max_n, 512), count, max_m, launched + it);
       chain.mark(1);
       // Gauss-Newton needs no error trials: the optimiser step rides on the linearisation launch (its last workgroup per pair).
       // Levenberg-Marquardt keeps its own launch: an error trial wants the 1024 threads of lm_solve_kernel.
@@ -928,7 +953,7 @@ void gorio_apd_destroy(gorio_apd_t* h) {
   hipFree(h->d_sub_in); hipFree(h->d_sub_out); hipFree(h->d_sub_vox); hipFree(h->d_sub_keys); hipFree(h->d_sub_counts); hipFree(h->d_sub_frames); hipFree(h->d_sub_bb); hipFree(h->d_sub_job);
   h->src.reset();
   h->tgt.reset();
-  hipFree(h->best_key); hipFree(h->seed); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
+  hipFree(h->best_key); hipFree(h->seed); hipFree(h->nn_work); hipFree(h->nn_plan); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
   hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_ijobs); hipFree(h->d_fit); hipFree(h->d_copy_jobs);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
   delete h;
@@ -1461,7 +1486,7 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
     int splits = 4096 / (waves > 0 ? waves : 1);
     splits = std::min(16, std::max(1, splits));
     while (splits & (splits - 1)) splits &= splits - 1;
-    launch_pruned(dim3((roundup(h->src->n, 512) + 255) / 256, splits, 1), h->stream, h->d_desc, bf);
+    launch_pruned(dim3((roundup(h->src->n, 512) + 255) / 256, splits, 1), h->stream, h->d_desc, bf, 0);
   } else {
     nn_search_kernel<<<dim3(nbx, d.nn_splits, 1), 256, 0, h->stream>>>(h->d_desc);
   }

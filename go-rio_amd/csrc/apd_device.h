@@ -85,7 +85,13 @@ struct PairDesc {
   double* partials;  // [nblk][28]
   int* seed;         // [src n_spad] by SORTED source position: original target index of the last search's winner (warm start of the next
                      // pruned search of the same align); read only when state->n_linearize > 0, any in-range value is valid
+  unsigned int* nn_work;  // [2][nn_wcap] cycles every query wave (64 sorted source points) spent in the pruned search: the launches of an align
+                          // alternate between the two halves, so that a plan can be made from a finished launch while the next one runs
+  unsigned int* nn_plan;  // [1 + 2 nn_wcap] work plan of the next pruned searches (nn_plan_kernel): [0] = number of entries, then one entry per
+                          // workgroup, heaviest first: wave << 8 | part << 4 | log2(parts)
   PairState* state;
+  int nn_wcap;
+  int pad0_;
   int nblk;          // ceil(src.n / 256)
   int nn_splits;     // target range split count for nn_search_kernel
   int nn_chunk;      // candidates per split (multiple of 16)

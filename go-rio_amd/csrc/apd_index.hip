@@ -458,207 +458,26 @@ __device__ unsigned long long g_search_stats[1024][24];
 #define STAT_INC(name) do { } while (0)
 #endif
 
-// 1-NN of every source point in the target, pruned.  One lane = one source point taken in MORTON order (a wave's 64 queries are
-// spatially compact).  grid: (ceil(n_spad_src / 256), splits, pairs), block 256.
-// Output: best_key[orig source index] = (float bits of d) << 32 | orig target index, exactly as nn_search_kernel.
-__global__ __launch_bounds__(256) void nn_search_pruned_v2_kernel(const PairDesc* __restrict__ descs, float bound_f) {
-  const PairDesc& pd = descs[blockIdx.z];
-  const PairState* __restrict__ st = pd.state;
-  if (st->done) return;
-  const SearchIndex& si = pd.src.idx;
-  const SearchIndex& ti = pd.tgt.idx;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= si.n) return;
-  if ((int)(blockIdx.x * 256) < pd.shard_lo || (int)(blockIdx.x * 256) >= pd.shard_hi) return;  // another rank's part of the source
-  const int lane = threadIdx.x & 63;
-  const int pq = p < si.n ? p : si.n - 1;
-  float qx, qy, qz;
-  transform_f(st->Tf, si.sx[pq], si.sy[pq], si.sz[pq], qx, qy, qz);
-  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
-  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
-  const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(ti.tbox);
-  // candidates farther than the correspondence gate can never be accepted (APD:183): start from the gate as the bound
-  unsigned long long best = ((unsigned long long)__float_as_uint(bound_f) << 32) | 0xffffffffull;
-  float bestd = bound_f;
-  // Warm start inside one align: the correspondence of the previous linearisation (APD:164-180 ran one Gauss-Newton step ago) is
-  // an ordinary candidate -- its distance under the CURRENT pose is evaluated with the same expression as any other point -- and
-  // almost always the winner or within a few centimetres of it, so the branch-and-bound starts from a tight bound.  The answer is
-  // unchanged (the minimum over all candidates does not depend on the order they are met in); only the work is.
-  if (st->n_linearize > 0 && p < si.n) {
-    const int pc = pd.corr[si.orig[pq]];
-    if (pc >= 0 && pc < pd.tgt.n) {
-      const float4 tp = pd.tgt.p4[pc];
-      const float d = sqdist3(qx, qy, qz, tp.x, tp.y, tp.z);
-      const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)pc;
-      if (key < best) {
-        best = key;
-        bestd = d;
-      }
-    }
-  }
-  STAT_ADD(5, 1);
-  const int ng = (ti.n_tiles + 63) / 64;
-  int g0 = (int)(((long)(blockIdx.x * 256 + (threadIdx.x & ~63)) * ng) / (si.n > 0 ? si.n : 1));
-  g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);
-  const int nsplit = gridDim.y;  // > 1 only when a launch has too few query waves to fill the chip: tile groups are dealt round-robin
-  const bool seeded = st->n_linearize > 0;
-  // WORK LIST: with a tight bound a lane needs ~2 tiles but the 64 lanes of a wave need ~11 different ones, so evaluating every
-  // needed tile for all lanes would waste 4/5 of the distance work.  Instead the tiles some lane needs are staged in LDS (up to
-  // kNnSlots per batch -- 8: the kernel is latency bound and 17 KB of LDS per workgroup keeps five waves per SIMD resident, 16 slots
-  // cost 30 % -- one float4 per point: x, y, z, original index) and each lane walks only ITS OWN tiles, reading candidates from its
-  // slot -- lanes of one instruction work on different tiles.  A tile is selected against the bound the lane had when the tile was
-  // tested (bounds tighten at every batch), a superset of what the final bound would select, so the result is unchanged.
-  constexpr int kNnSlots = 8;
-  __shared__ float4 s_pts[4][kNnSlots][33];  // 33: slots 528 B apart -> lanes on different slots hit different banks
-  const int wave = threadIdx.x >> 6;
-  const __attribute__((address_space(1))) float* gx = (const __attribute__((address_space(1))) float*)ti.sx;
-  const __attribute__((address_space(1))) float* gy = (const __attribute__((address_space(1))) float*)ti.sy;
-  const __attribute__((address_space(1))) float* gz = (const __attribute__((address_space(1))) float*)ti.sz;
-  const __attribute__((address_space(1))) int* go = (const __attribute__((address_space(1))) int*)ti.orig;
-  // The first, unseeded launch of an align has only the gate as its bound.  It runs the same work list, but flushes its first
-  // batch after two tiles so that every lane owns a real bound before the remaining tiles are tested.
-  int flush_at = seeded ? kNnSlots : 2;
-  STAT_DECL(wave_rounds);
-  unsigned int mneed = 0u;  // slots of the current batch this lane must visit
-  int slot_tile = 0;        // lane s: tile held by slot s
-  int nslots = 0;           // wave-uniform
-  auto flush = [&]() {
-    for (int s0 = 0; s0 < nslots; s0 += 2) {  // two slots per pass: lanes 0-31 / 32-63 bring one point each
-      const int my = s0 + (lane >> 5);
-      const int tile = __shfl(slot_tile, my < nslots ? my : s0, 64);
-      if (my < nslots) {
-        const int j = tile * 32 + (lane & 31);
-        s_pts[wave][my][lane & 31] = make_float4(gx[j], gy[j], gz[j], __int_as_float(go[j]));
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    STAT_ADD(3, __builtin_popcount(mneed));  // lane 0's own item count (a sample of the per-lane mean)
-    while (__ballot(mneed != 0u)) {
-      STAT_ADD(4, 1);
-      STAT_INC(wave_rounds);
-      if (mneed != 0u) {
-        const int sl = __builtin_ctz(mneed);
-        mneed &= mneed - 1u;
-        const float4* __restrict__ cp = s_pts[wave][sl];
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-          const float4 c = cp[k];
-          const float d = sqdist3(qx, qy, qz, c.x, c.y, c.z);
-          const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)__float_as_uint(c.w);
-          best = key < best ? key : best;
-        }
-      }
-    }
-    bestd = __uint_as_float((unsigned int)(best >> 32));
-    nslots = 0;
-    __builtin_amdgcn_wave_barrier();
-  };
-  // THREE levels.  A 1 M-point map has 31 250 tiles in 489 groups of 64; testing every group's tile boxes costs a wave 29 k
-  // instructions before it has looked at a single point.  So the super-tile boxes (16 tiles = 512 points, four per group) are tested
-  // first, 64 per instruction (one per lane) against the box of the wave's queries and its loosest bound: a bit mask of the groups
-  // that can matter at all.  Only those groups get the tile-level test, nearest group (in index order, which follows space) first.
-  constexpr int kGroupWords = 32;  // mask words per pass: 2048 groups = 4.2 M target points; larger targets take several passes
-  __shared__ unsigned long long s_gmask[4][kGroupWords];
-  const float4* __restrict__ sb4 = reinterpret_cast<const float4*>(ti.sbox);
-  for (int c0 = 0; c0 < ng; c0 += kGroupWords * 64) {
-    const int cg = ng - c0 < kGroupWords * 64 ? ng - c0 : kGroupWords * 64;
-    const int nwords = (cg + 63) >> 6;
-    const float wb0 = wave_max(bestd);
-    for (int w = 0; w < nwords; ++w) {
-      unsigned long long word = 0ull;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {  // one ballot = 64 super tiles = 16 groups
-        const int gbase = c0 + w * 64 + q4 * 16;
-        if (gbase < ng) {
-          const int sl = gbase * 4 + lane;
-          bool pass = false;
-          if (sl < ti.n_super) pass = box_box_bound(qlo, qhi, sb4[2 * (size_t)sl], sb4[2 * (size_t)sl + 1]) <= wb0;
-          unsigned long long m = __ballot(pass);
-          m |= m >> 1;
-          m |= m >> 2;  // bit 4 j: any of the four super tiles of group j
-          m &= 0x1111111111111111ull;
-          m = (m | (m >> 3)) & 0x0303030303030303ull;
-          m = (m | (m >> 6)) & 0x000f000f000f000full;
-          m = (m | (m >> 12)) & 0x000000ff000000ffull;
-          m = (m | (m >> 24)) & 0xffffull;
-          word |= m << (q4 * 16);
-        }
-      }
-      if (lane == 0) s_gmask[wave][w] = word;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    int gl = g0 - c0;  // where near neighbours are expected, relative to this pass
-    gl = gl < 0 ? 0 : (gl >= cg ? cg - 1 : gl);
-    const int w0 = gl >> 6;
-    for (int v = 0; v < 2 * nwords; ++v) {
-      const int woff = (v + 1) >> 1;
-      const int w = (v & 1) ? w0 - woff : w0 + woff;
-      if (w < 0 || w >= nwords) continue;
-      const unsigned long long mw = s_gmask[wave][w];
-      unsigned long long gm = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned int)(mw >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned int)mw);
-      const int pivot = w == w0 ? (gl & 63) : (w > w0 ? 0 : 63);
-      while (gm) {
-        // the set bit nearest to the pivot: groups are visited outward from where the queries sit, so the bound tightens early
-        const unsigned long long up = gm & (~0ull << pivot), dn = gm & ~(~0ull << pivot);
-        const int bu = up ? __builtin_ctzll(up) : 1000, bd = dn ? 63 - __builtin_clzll(dn) : -1000;
-        const int bit = (bu - pivot) <= (pivot - bd) ? bu : bd;
-        gm &= ~(1ull << bit);
-        const int g = c0 + w * 64 + bit;
-        if (nsplit > 1 && (g % nsplit) != (int)blockIdx.y) continue;
-        const int tl = g * 64 + lane;
-        float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
-        if (tl < ti.n_tiles) {
-          lo = tb4[2 * (size_t)tl];
-          hi = tb4[2 * (size_t)tl + 1];
-        }
-        const float wb = wave_max(bestd);
-        unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) <= wb);
-        STAT_ADD(7, __builtin_popcountll(mask));
-        while (mask) {
-          const int tlane = __builtin_ctzll(mask);
-          mask &= mask - 1;
-          const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
-          const bool need = box_bound(qx, qy, qz, bx) <= bestd;
-          if (__ballot(need) == 0) continue;
-          STAT_ADD(6, 1);
-          if (need) mneed |= 1u << nslots;
-          if (lane == nslots) slot_tile = g * 64 + tlane;
-          if (++nslots >= flush_at) {
-            flush();
-            flush_at = kNnSlots;
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // the mask words are rewritten by the next pass
-  }
-  if (nslots > 0) flush();
-#ifdef GORIO_STATS
-  STAT_MAX(2, wave_rounds);
-  STAT_ADD(1, wave_rounds > 64 ? 1 : 0);
-  STAT_ADD(0, wave_rounds > 64 ? wave_rounds : 0);
-#endif
-  if (p < si.n && (unsigned int)best != 0xffffffffu) {
-    if (nsplit > 1) atomicMin(pd.best_key + si.orig[p], best);
-    else pd.best_key[si.orig[p]] = best;
-  }
-}
-
-// ----------------------------------------------------------------------------------------------- 1-NN, round 3 form
+// ----------------------------------------------------------------------------------------------- 1-NN correspondences, pruned
 //
-// Same answer, same tile tests; what changed is WHERE the instructions go (the round-2 kernel filled 52 % of the VALU issue time alone,
-// 61 % of it with half-rate instructions):
-//   * wave reductions by DPP (v_max_u32 row_ror / row_bcast on order-preserving integer keys) instead of six ds_bpermute round trips each;
-//     the results are wave-uniform SGPR values.
-//   * the box of a candidate tile arrives by a scalar load (s_load_dwordx8, prefetched one candidate ahead) instead of six v_readlane, and
-//     its per-lane lower bound is max3(lo - q, q - hi, 0) per axis: 11 full-rate + 4 half-rate instructions (was 8 + 12 + 6 readlanes).
+// 1-NN of every source point in the target (APD:164-180), same packed-key output as nn_search_kernel.  One lane = one source point taken in
+// the source's own sorted order (a wave's 64 queries are spatially compact).  Round-3 rewrite.  The round-2 kernel filled 52 % of the VALU
+// issue time alone, 61 % of it with half-rate instructions, its waves were parked 40 % of their life, and -- what the counters did not
+// show -- a launch lasted as long as its SLOWEST wave (5 - 25 x the mean).  What changed, in the order it paid:
+//   * WORK PLAN (nn_plan_kernel below): every wave records the cycles it took; from the third search of an align on, waves that were slow
+//     in the second one are cut into 2 .. 16 parts and the parts are dispatched heaviest first.
+//   * ONE-WAVE WORKGROUPS: the waves of a workgroup never cooperate, but a workgroup keeps its LDS (the occupancy limit here) until its
+//     slowest wave ends.
+//   * FEWER DEPENDENT ROUND TRIPS (a wave is a chain of L2 / Infinity-Cache round trips of 1-2 k cycles each): everything that does not
+//     depend on the bound is loaded at the start, ahead of the seed chain (query, seed, boxes of the first 64 blocks, of the home block's
+//     super tiles and of the home group's tiles); the next group's tile boxes are in flight while this group's tiles are tested; loads are
+//     unconditional with clamped indices, validity being applied to the ballots (a load inside a branch makes the compiler wait for every
+//     outstanding load at the join); the optimiser state is read through the scalar cache, not by flat loads.
+//   * a BLOCK level (32 768 points) above the super tiles: a wave against a 1 M-point map tests 31 block boxes and the super tiles of
+//     the few surviving blocks instead of all 1954 super tiles; the group mask of a pass lives in registers, not in LDS.
 //   * the (lane, tile) evaluations of a batch are COMPACTED: the round-2 walk took max-over-lanes rounds per batch (4.7 rounds of 64
 //     lanes per wave for 2.2 tiles per lane); now every (query, slot) pair becomes an item of a list in LDS and the wave evaluates
-//     64 items per round whatever query they belong to (the query is re-read from LDS).
+//     64 items per round whatever query they belong to (the query is re-read from LDS): 3.6 rounds.
 //   * an item keeps only the MINIMUM distance of its 32 candidates (v_min3_u32 on the float bits: 0.56 half-rate instruction per
 //     candidate instead of a 64-bit compare and two selects) and which 8-candidate groups hold it; items meet in an LDS atomic
 //     min on (distance bits, slot, groups); the owning lane then re-evaluates only the winning group to recover the ORIGINAL index
@@ -666,12 +485,16 @@ __global__ __launch_bounds__(256) void nn_search_pruned_v2_kernel(const PairDesc
 //     index -- raise a flag and that lane re-walks its slots with full (distance, index) keys.
 //   * the previous correspondence (by sorted source position, pd.seed) seeds only the BOUND; its index is found again when its tile
 //     is evaluated (the tile's box bound never exceeds the distance of a point inside it, so the tile is always taken).
-//   * tiles are staged from one float4 array (x, y, z, original index) of the index: one 16-byte load per point instead of four.
+//   * wave reductions by DPP (v_max_u32 row_ror / row_bcast on order-preserving integer keys) instead of six ds_bpermute round trips each;
+//     the per-lane lower bound of a tile box is max3(lo - q, q - hi, 0) per axis (11 full-rate + 4 half-rate instructions, was 8 + 12);
+//     tiles are staged from one float4 array (x, y, z, original index): one 16-byte load per point instead of four.
+// Measured and dropped: the candidate tile's box by a prefetched scalar load instead of six v_readlane (every test then waits ~ 400 cycles
+// for the scalar cache); 12 or 16 slots per batch (fewer flushes, but the LDS they take costs a wave per SIMD: 2.55 / 2.67 vs 2.50 ms).
 #ifndef GORIO_NN_SLOTS
 #define GORIO_NN_SLOTS 8
 #endif
 #ifndef GORIO_NN_WAVES
-#define GORIO_NN_WAVES 5
+#define GORIO_NN_WAVES 5  // 96 registers; the 36 bytes of scratch this costs were measured: 2.00 vs 2.10 ms per 20 launches with 4
 #endif
 #ifndef GORIO_NN_BLOCK
 #define GORIO_NN_BLOCK 64  // threads per workgroup: the waves of a workgroup never cooperate, and a workgroup holds its LDS until its SLOWEST wave ends
@@ -747,7 +570,7 @@ __device__ __forceinline__ void lds_read8_b128(v4f_t (&c)[8], unsigned int addr)
       : "memory");
 }
 
-__global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_NN_WAVES, GORIO_NN_WAVES))) void nn_search_pruned_kernel(const PairDesc* __restrict__ descs, float bound_f) {
+__global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_NN_WAVES, GORIO_NN_WAVES))) void nn_search_pruned_kernel(const PairDesc* __restrict__ descs, float bound_f, int mode) {
   const PairDesc& pd = descs[blockIdx.z];
   // the optimiser state is constant while this kernel runs: read it through the scalar cache (a generic pointer would make these flat
   // loads, whose completion the compiler can only wait for together with every other outstanding load)
@@ -755,9 +578,23 @@ __global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_
   if (st->done) return;
   const SearchIndex& si = pd.src.idx;
   const SearchIndex& ti = pd.tgt.idx;
-  const int p = blockIdx.x * kNnBlock + threadIdx.x;
-  if (blockIdx.x * kNnBlock >= si.n) return;
-  if ((int)(blockIdx.x * kNnBlock) < pd.shard_lo || (int)(blockIdx.x * kNnBlock) >= pd.shard_hi) return;  // another rank's part of the source (bounds are multiples of 256)
+  // Which query wave, and which share of its tile groups, this wave of the grid works on.  Natural launches (mode bit 1 clear): wave =
+  // position in the grid, the groups dealt over gridDim.y workgroups.  Planned launches: the entry of nn_plan_kernel's list -- waves that
+  // were slow in the previous search come first and are cut into more parts (a launch lasts as long as its slowest wave).
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+  // (made wave-uniform for the compiler right here: everything the traversal state depends on must stay in scalar registers)
+  int wq = __builtin_amdgcn_readfirstlane(blockIdx.x * (kNnBlock / 64) + (threadIdx.x >> 6)), part = blockIdx.y, nparts = gridDim.y;
+  if (mode & 2) {
+    const __attribute__((address_space(4))) unsigned int* plan = (const __attribute__((address_space(4))) unsigned int*)pd.nn_plan;
+    if ((unsigned int)wq >= plan[0]) return;
+    const unsigned int e = plan[1 + wq];
+    wq = (int)(e >> 8);
+    part = (int)((e >> 4) & 15u);
+    nparts = 1 << (e & 7u);
+  }
+  const int p = wq * 64 + (threadIdx.x & 63);
+  if (wq * 64 >= si.n) return;
+  if (wq * 64 < pd.shard_lo || wq * 64 >= pd.shard_hi) return;  // another rank's part of the source (bounds are multiples of 256)
   constexpr int S = GORIO_NN_SLOTS;
   constexpr unsigned int kNone = 0xffffffffu;
   static_assert(S >= 2 && S <= 16, "slot index is packed into 4 bits");
@@ -776,7 +613,7 @@ __global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_
   const global_f4p t4(ti.s4);
   const int ng = (ti.n_tiles + 63) / 64;
   const int n_blk = (ti.n_super + 63) >> 6;  // block = 64 super tiles = 16 groups = 32 768 points
-  int g0 = (int)(((long)(blockIdx.x * kNnBlock + (threadIdx.x & ~63)) * ng) / (si.n > 0 ? si.n : 1));
+  int g0 = (int)(((long)(wq * 64) * ng) / (si.n > 0 ? si.n : 1));
   g0 = __builtin_amdgcn_readfirstlane(g0 < ng ? g0 : ng - 1);
   // ---- every load that does not depend on the bound is issued NOW, ahead of the seed chain (the kernel is a chain of dependent
   // round trips to L2, 1-2 k cycles each under load): the query, its seed, the boxes of the first 64 blocks, of the super tiles of the
@@ -835,8 +672,8 @@ __global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_
   STAT_LOCAL(5, 1);
   // workgroups of one query wave (gridDim.y > 1 only when a launch has too few query waves to fill the chip, or for big targets) share the
   // groups round-robin: bit pattern of "my" groups inside any 64-group word (gridDim.y is a power of two <= 16)
-  const int nsplit = gridDim.y;
-  unsigned long long mine = 1ull << (blockIdx.y & 63);
+  const int nsplit = nparts;
+  unsigned long long mine = 1ull << (part & 63);
   for (int sft = nsplit; sft < 64; sft <<= 1) mine |= mine << sft;
   // The first, unseeded launch of an align has only the gate as its bound: it flushes its first batch after two tiles so that every lane
   // owns a real bound before the remaining tiles are tested.
@@ -1090,9 +927,87 @@ __global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_
     else pd.best_key[oi] = best;
     pd.seed[p] = (int)(unsigned int)best;  // next launch's warm start (with nsplit > 1 whichever workgroup writes last: any target point is valid)
   }
+#ifndef GORIO_NN_NOWORK
+  if ((threadIdx.x & 63) == 0) {  // what this wave cost, for the plan of the next launches
+    const unsigned int dt = (unsigned int)(__builtin_amdgcn_s_memtime() - t_start);
+    unsigned int* wk = pd.nn_work + (size_t)(mode & 1) * pd.nn_wcap + wq;
+    if (nparts == 1) *wk = dt;  // (this half was zeroed by the previous launch, or by arm_keys_kernel)
+    else atomicAdd(wk, dt);
+    if (part == 0) pd.nn_work[(size_t)((mode & 1) ^ 1) * pd.nn_wcap + wq] = 0u;
+  }
+#endif
   STAT_PHASE(7);
   STAT_CLOCK_FLUSH();
 }
+
+// Work plan of the next pruned searches of every pair from the cycles its query waves took in a finished one (nn_work[buf]).  A launch lasts
+// as long as its slowest wave, and a few waves (far returns whose bound ball is full of target points) take 5 - 25 x the mean: each wave is
+// cut into 1, 2, 4, 8 or 16 parts (the parts share the wave's tile groups round-robin) so that no part exceeds about half the time the
+// launch would take if its work were spread perfectly, and the parts are listed heaviest first (dispatch follows the list).  The plan
+// changes the schedule, never a result.  grid: pairs, block 256.
+__global__ __launch_bounds__(256) void nn_plan_kernel(const PairDesc* __restrict__ descs, int buf, int npairs) {
+  const PairDesc& pd = descs[blockIdx.x];
+  const int nw = (pd.src.idx.n + 63) / 64;
+  const unsigned int* __restrict__ w = pd.nn_work + (size_t)buf * pd.nn_wcap;
+  unsigned int* __restrict__ plan = pd.nn_plan;
+  __shared__ unsigned long long s_tot;
+  __shared__ unsigned int s_cnt[32], s_off[32], s_entries;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_tot = 0ull;
+  if (tid < 32) s_cnt[tid] = 0u;
+  __syncthreads();
+  unsigned long long loc = 0ull;
+  for (int i = tid; i < nw; i += 256) loc += w[i];
+  atomicAdd(&s_tot, loc);
+  __syncthreads();
+  // budget of one part: half of (all work of the batch / wave slots of the chip), assuming the pairs of a batch are alike
+  unsigned long long T = s_tot * (unsigned long long)npairs / 10240ull;
+  if (T < 4096ull) T = 4096ull;
+  int max_lg = 4;
+  auto parts_of = [&](unsigned int wi) -> int {
+    int lg = 0;
+    while (lg < max_lg && (unsigned long long)wi > (T << lg)) ++lg;
+    return lg;  // log2(parts)
+  };
+  for (int attempt = 0; attempt < 9; ++attempt) {  // at most 2 nw entries (the grid of a planned launch covers exactly that many)
+    if (attempt == 8) max_lg = 0;  // never reached with sane work figures: one part per wave always fits
+    if (tid == 0) s_entries = 0u;
+    __syncthreads();
+    unsigned int mine = 0u;
+    for (int i = tid; i < nw; i += 256) mine += 1u << parts_of(w[i]);
+    atomicAdd(&s_entries, mine);
+    __syncthreads();
+    const bool ok = s_entries <= 2u * (unsigned int)nw;
+    __syncthreads();
+    if (ok) break;
+    T *= 2ull;
+  }
+  // counting sort by the work of a part, heaviest bucket first (32 buckets of log2)
+  for (int i = tid; i < nw; i += 256) {
+    const int lg = parts_of(w[i]);
+    const unsigned int pw = w[i] >> lg;
+    const int bkt = 31 - (pw ? 31 - __builtin_clz(pw) : 0);
+    atomicAdd(&s_cnt[bkt], 1u << lg);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned int o = 0u;
+    for (int q = 0; q < 32; ++q) {
+      s_off[q] = o;
+      o += s_cnt[q];
+    }
+    plan[0] = o;
+  }
+  __syncthreads();
+  for (int i = tid; i < nw; i += 256) {
+    const int lg = parts_of(w[i]);
+    const unsigned int pw = w[i] >> lg;
+    const int bkt = 31 - (pw ? 31 - __builtin_clz(pw) : 0);
+    const unsigned int at = atomicAdd(&s_off[bkt], 1u << lg);
+    for (int q = 0; q < (1 << lg); ++q) plan[1 + at + q] = ((unsigned int)i << 8) | ((unsigned int)q << 4) | (unsigned int)lg;
+  }
+}
+
 
 // Insertion of a packed key ((float bits of d) << 32 | original index; d >= 0, so the integer order IS the lexicographic
 // (distance, index) order) into an ascending register list: a compare and two 64-bit selects per slot.
