@@ -51,7 +51,7 @@ APD_SYMBOLS = [
     "gorio_apd_get_target_covariances", "gorio_apd_calculate_covariances", "gorio_apd_get_knn_indices", "gorio_apd_align",
     "gorio_apd_align_batch", "gorio_apd_linearize", "gorio_apd_compute_error", "gorio_apd_get_correspondences",
     "gorio_apd_get_mahalanobis", "gorio_apd_transform_source", "gorio_apd_fitness_score", "gorio_apd_set_profiling",
-    "gorio_apd_get_stage_times", "gorio_apd_set_target_shared", "gorio_comm_get_unique_id", "gorio_apd_comm_init", "gorio_apd_comm_destroy", "gorio_apd_debug_set_shard", "gorio_apd_set_target_submap", "gorio_apd_get_target_points",
+    "gorio_apd_get_stage_times", "gorio_apd_set_target_shared", "gorio_comm_get_unique_id", "gorio_apd_comm_init", "gorio_apd_comm_destroy", "gorio_apd_debug_set_shard", "gorio_apd_debug_set_schedule", "gorio_apd_set_target_submap", "gorio_apd_get_target_points",
 ]
 
 _lib = None
@@ -222,6 +222,9 @@ class ApdGicp:
 
     def debugSetShard(self, world_size, rank):  # noqa: N802 -- test hook: the partition of a rank without the collectives
         _check(self._h, self._lib.gorio_apd_debug_set_shard(self._h, int(world_size), int(rank)))
+
+    def debugSetSchedule(self, fuse_step=True, plan_search=True):  # noqa: N802 -- test hook: the two schedule optimisations of a GN align
+        _check(self._h, self._lib.gorio_apd_debug_set_schedule(self._h, int(bool(fuse_step)), int(bool(plan_search))))
 
     def commDestroy(self):  # noqa: N802
         _check(self._h, self._lib.gorio_apd_comm_destroy(self._h))

@@ -49,6 +49,7 @@ struct DevCloud {
   int n = 0, n_pad = 0, cap = 0;
   bool present = false;
   int cov_count = 0;       // == source_covs_.size(): n when valid, 0 when stale
+  int cov_k = -1, cov_reg = -1;  // k_correspondences / regularization the covariances were ESTIMATED with; -1: supplied by set_*_covariances
   // exact search accelerator (GORIO_SEARCH_PRUNED)
   SearchIndex idx = SearchIndex{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   unsigned long long* keys = nullptr;
@@ -112,6 +113,7 @@ struct gorio_apd {
   ncclComm_t comm = nullptr;
   int comm_world = 1, comm_rank = 0;
   bool shard_only = false;  // gorio_apd_debug_set_shard: the source partition of a rank without the collectives (test hook)
+  bool fuse_step = true, plan_search = true;  // gorio_apd_debug_set_schedule
   double* d_red = nullptr;  // [32] all-reduce buffer: 28 sums of a linearisation, [28] trial error, [29] scratch
   std::string err;
   // profiling
@@ -570,8 +572,9 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     dim3 gp((roundup(max_n, 512) + 255) / 256, 1, njobs);
     if (K == 20) {
       if (pruned) {
-        knn_kth_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
-        knn_collect_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);
+        const dim3 gs(gp.x * (256 / kKnnBlock), 1, njobs);
+        knn_kth_kernel<20><<<gs, kKnnBlock, 0, lead->stream>>>(lead->d_jobs);
+        knn_collect_kernel<20><<<gs, kKnnBlock, 0, lead->stream>>>(lead->d_jobs);
         knn_pruned_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);  // only the waves knn_collect_kernel flagged (massive ties) do anything
       } else {
         knn_partial_kernel<20><<<g1, 256, 0, lead->stream>>>(lead->d_jobs);
@@ -586,7 +589,11 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     }
   }
   HIP_TRY(lead, hipGetLastError());
-  for (auto& t : todo) t.second->cov_count = t.second->n;
+  for (auto& t : todo) {
+    t.second->cov_count = t.second->n;
+    t.second->cov_k = k;
+    t.second->cov_reg = lead->params.regularization;
+  }
   return GORIO_OK;
 }
 
@@ -610,7 +617,7 @@ void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_s
   if (lead->params.search == GORIO_SEARCH_PRUNED) {
     const double thr = lead->params.corr_dist_threshold;
     const long waves = (long)count * ((max_src_spad + 63) / 64);
-    static const bool no_plan = std::getenv("GORIO_NN_NO_PLAN") != nullptr;  // debug switch: every search with the natural schedule
+    const bool no_plan = !lead->plan_search;  // gorio_apd_debug_set_schedule
     const bool planned = launch_index >= 2 && !lead->comm && !lead->shard_only && !no_plan;
     if (planned) {
       launch_pruned(dim3(2 * ((max_src_spad + 255) / 256), 1, count), lead->stream, d_desc, gate_bound(thr * thr), 2 | (launch_index & 1));
@@ -631,10 +638,18 @@ void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_s
   }
 }
 
+// a target shared with other handles carries ONE set of covariances: a sharer whose k_correspondences / regularization differ from the ones
+// they were estimated with would silently register with another object's covariances (the reference estimates them per object, APD:149-154)
+bool shared_cov_mismatch(const gorio_apd* h) {
+  const DevCloud& t = *h->tgt;
+  return h->tgt.use_count() > 1 && t.cov_count == t.n && t.cov_k >= 0 && (t.cov_k != h->params.k_correspondences || t.cov_reg != h->params.regularization);
+}
+
 int check_ready(gorio_apd* h) {
   if (!h->src->present) return fail(h, GORIO_ERR_STATE, "no input source set (setInputSource)");
   if (!h->tgt->present) return fail(h, GORIO_ERR_STATE, "no input target set (setInputTarget)");
   const gorio_apd_params& p = h->params;
+  if (shared_cov_mismatch(h)) return fail(h, GORIO_ERR_INVALID, "the shared target's covariances were estimated with another k_correspondences / regularization: give this handle a target of its own (setInputTarget)");
   if (p.k_correspondences < 1 || p.k_correspondences > 32) return fail(h, GORIO_ERR_UNSUPPORTED, "k_correspondences must be in [1, 32]");
   if (p.regularization < 0 || p.regularization > 4) return fail(h, GORIO_ERR_UNSUPPORTED, "unknown regularization method (the reference aborts here, APD:389-391)");
   if (h->src->cov_count != h->src->n && h->src->n < p.k_correspondences) return fail(h, GORIO_ERR_INVALID, "source cloud has fewer points than k_correspondences (undefined in the reference, APD:366-369)");
@@ -844,7 +859,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
   }
   int launched = 0;
   int chunk_iters = 4;
-  const bool fuse_gn = lead->params.optimizer != GORIO_OPT_LEVENBERG_MARQUARDT;
+  const bool fuse_gn = lead->params.optimizer != GORIO_OPT_LEVENBERG_MARQUARDT && lead->fuse_step;
   const int max_it = lead->params.max_iterations;
   while (launched < max_it) {
     const int todo_it = std::min(chunk_iters, max_it - launched);
@@ -935,6 +950,11 @@ int gorio_apd_create(gorio_apd_t** out, int device) {
   h->src->device = h->tgt->device = device;
   gorio_apd_default_params(&h->params);
   h->stream = device_stream(device);
+  {  // the fence-free "last workgroup runs the optimiser step" hand-over relies on how gfx950 writes through and acknowledges sc1 stores across
+     // its XCD L2s: it was validated there and is switched off on anything else (the step then takes its own launch)
+    hipDeviceProp_t prop;
+    h->fuse_step = hipGetDeviceProperties(&prop, device) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+  }
   if (!h->stream || hipMalloc(&h->d_state, sizeof(PairState)) != hipSuccess ||
       hipMalloc(&h->d_fit, sizeof(double) * 4) != hipSuccess || hipMalloc(&h->d_red, sizeof(double) * 32) != hipSuccess) {
     delete h;
@@ -1070,6 +1090,11 @@ int gorio_apd_set_target_shared(gorio_apd_t* h, gorio_apd_t* owner) {
   if (!h || !owner) return GORIO_ERR_INVALID;
   if (h->device != owner->device) return fail(h, GORIO_ERR_INVALID, "set_target_shared: both handles must live on one device");
   if (!owner->tgt->present) return fail(h, GORIO_ERR_STATE, "set_target_shared: the owner has no input target");
+  {
+    const DevCloud& t = *owner->tgt;
+    if (t.cov_count == t.n && t.cov_k >= 0 && (t.cov_k != h->params.k_correspondences || t.cov_reg != h->params.regularization))
+      return fail(h, GORIO_ERR_INVALID, "set_target_shared: the owner's covariances were estimated with another k_correspondences / regularization than this handle's");
+  }
   h->tgt = owner->tgt;  // points, covariances, search index: one copy on the device, alive until the last handle lets go of it
   h->corr_valid = false;
   return GORIO_OK;
@@ -1248,6 +1273,7 @@ static int set_covs(gorio_apd* h, DevCloud& c, const double* cov, int n) {
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   c.cov_count = n;
+  c.cov_k = c.cov_reg = -1;
   c.knn_valid = false;  // these covariances did not come from a k-NN search of this library
   return GORIO_OK;
 }
@@ -1444,6 +1470,8 @@ int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out
 int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double inlier_dist, double* score, double* inlier_fraction) {
   if (!h || !T || !score) return GORIO_ERR_INVALID;
   if (!h->src->present || !h->tgt->present) return fail(h, GORIO_ERR_STATE, "fitness_score: clouds not set");
+  if ((h->comm || h->shard_only) && h->comm_world > 1)
+    return fail(h, GORIO_ERR_STATE, "fitness_score: this handle searches only its rank's share of the source (gorio_apd_comm_init); score the pose on an unsharded handle");
   HIP_TRY(h, hipSetDevice(h->device));
   int rc = ensure_points(h, h->src->n);
   if (rc) return rc;
@@ -1542,6 +1570,13 @@ int gorio_apd_debug_set_shard(gorio_apd_t* h, int world_size, int rank) {
   h->comm_rank = rank;
   h->shard_only = world_size > 1;
   h->corr_valid = false;
+  return GORIO_OK;
+}
+
+int gorio_apd_debug_set_schedule(gorio_apd_t* h, int fuse_step, int plan_search) {
+  if (!h) return GORIO_ERR_INVALID;
+  h->fuse_step = fuse_step != 0;
+  h->plan_search = plan_search != 0;
   return GORIO_OK;
 }
 

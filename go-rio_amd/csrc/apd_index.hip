@@ -1141,15 +1141,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 //                       (covariance_from_list) as before.
 // A wave in which some lane meets more than CAP candidates at or below its d_k (only with many exactly equal distances: lattices,
 // duplicated points) flags itself in job.redo and is redone by knn_pruned_kernel, so the result is exact for every input.
-// grid of both: (ceil(n_spad / 256), 1, clouds), block 256.
+// grid of both: (ceil(n_spad / kKnnBlock), 1, clouds), block kKnnBlock (one wave: the waves never cooperate, see nn_search_pruned_kernel).
+#ifndef GORIO_KNN_BLOCK
+#define GORIO_KNN_BLOCK 64
+#endif
+constexpr int kKnnBlock = GORIO_KNN_BLOCK;
 
 template <int K>
-__global__ __launch_bounds__(256) void knn_kth_kernel(const KnnJob* __restrict__ jobs) {
+__global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __restrict__ jobs) {
   const KnnJob& job = jobs[blockIdx.z];
   const SearchIndex& si = job.cloud.idx;
   const int n = si.n;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= n) return;
+  const int p = blockIdx.x * kKnnBlock + threadIdx.x;
+  if (blockIdx.x * kKnnBlock >= n) return;
   const int lane = threadIdx.x & 63;
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
@@ -1160,7 +1164,7 @@ __global__ __launch_bounds__(256) void knn_kth_kernel(const KnnJob* __restrict__
   const scalar_fp tz = as_scalar(si.sz);
   const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
   const int ng = (si.n_tiles + 63) / 64;
-  const int own_tile = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + (threadIdx.x & ~63)) / 32);
+  const int own_tile = __builtin_amdgcn_readfirstlane((blockIdx.x * kKnnBlock + (threadIdx.x & ~63)) / 32);
   const int g0 = own_tile / 64;
   float D[K];  // the K smallest distances met so far, ascending
 #pragma unroll
@@ -1212,12 +1216,12 @@ __global__ __launch_bounds__(256) void knn_kth_kernel(const KnnJob* __restrict__
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void knn_collect_kernel(const KnnJob* __restrict__ jobs) {
+__global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __restrict__ jobs) {
   const KnnJob& job = jobs[blockIdx.z];
   const SearchIndex& si = job.cloud.idx;
   const int n = si.n;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= n) return;
+  const int p = blockIdx.x * kKnnBlock + threadIdx.x;
+  if (blockIdx.x * kKnnBlock >= n) return;
   const int lane = threadIdx.x & 63;
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
@@ -1229,7 +1233,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const KnnJob* __restri
   const scalar_ip to = (scalar_ip)si.orig;
   const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
   constexpr int CAP = K + 4;
-  __shared__ unsigned long long s_buf[CAP][256];  // keys at or below d_k, one column per lane (bank = lane: conflict free)
+  __shared__ unsigned long long s_buf[CAP][kKnnBlock];  // keys at or below d_k, one column per lane (bank = lane: conflict free)
   const int ng = (si.n_tiles + 63) / 64;
   const float dk = job.kth[p];
   int cnt = 0;
@@ -1266,7 +1270,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const KnnJob* __restri
     }
   }
   const bool redo = __ballot(cnt > CAP) != 0ull;
-  if (lane == 0) job.redo[(blockIdx.x * 256 + threadIdx.x) >> 6] = redo ? 1 : 0;
+  if (lane == 0) job.redo[(blockIdx.x * kKnnBlock + threadIdx.x) >> 6] = redo ? 1 : 0;
   if (redo) return;
   // sort the buffered keys (ties fall to the lower original index, surplus ties beyond K drop off the end)
   unsigned long long L[K];

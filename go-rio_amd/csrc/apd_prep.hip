@@ -31,12 +31,14 @@ __global__ __launch_bounds__(256) void radius_neighbours_kernel(CloudView cloud,
   const int lane = threadIdx.x & 63;
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
-  // DBSCAN_simple.h:36-39, 65-67: std::sqrt of a float expression (float), then double arithmetic
+  // DBSCAN_simple.h:36-39: the seed radius stores std::sqrt(float expression) in a double and continues in double; DBS:65-67: the
+  // expansion radius evaluates (std::sqrt(float) - 1) / 100 entirely in FLOAT and only adds the double eps_ in double
   float n2 = qx * qx;
   n2 = n2 + qy * qy;
   n2 = n2 + qz * qz;
   const double norm = (double)sqrtf(n2);
-  const double r_seed = fabs(norm - 1) / 50 + a.eps, r_exp = (norm - 1) / 100 + a.eps;
+  const float ef = (sqrtf(n2) - 1.0f) / 100.0f;
+  const double r_seed = fabs(norm - 1) / 50 + a.eps, r_exp = (double)ef + a.eps;
   const float r2s = p < n ? (float)(r_seed * r_seed) : 0.0f, r2e = (float)(r_exp * r_exp);
   const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
   const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};

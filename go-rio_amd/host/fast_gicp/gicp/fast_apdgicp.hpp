@@ -75,6 +75,14 @@ public:
     regularization_method_ = RegularizationMethod::PLANE;
     const int rc = gorio_apd_create(&handle_, device);
     if (rc != GORIO_OK) throw std::runtime_error("FastAPDGICP: no usable HIP device (gorio_apd_create failed, code " + std::to_string(rc) + "); there is no CPU fallback");
+    // pcl::Registration::align() -> initCompute() rebuilds its CPU kd-tree for every new target (PCL 1.10 registration.hpp:
+    // `if (target_cloud_updated_ && !force_no_recompute_) tree_->setInputCloud(target_)`): tens of milliseconds for a 100 k-point map,
+    // more than the whole GPU registration, for a tree this class never searches.  So the base class gets a tree that is built only if
+    // somebody actually uses getSearchMethodTarget() (the inlier loop of scan_matching_odometry_nodelet.cpp:679-689 does; prefer
+    // getInlierFraction(), which runs on the GPU), and is told not to rebuild it.
+    typename pcl::Registration<PointSource, PointTarget, Scalar>::KdTreePtr tree(new LazyTargetTree());
+    lazy_tree_ = static_cast<LazyTargetTree*>(tree.get());  // owned by the base class' tree_ from here on
+    this->setSearchMethodTarget(tree, /*force_no_recompute=*/true);
   }
   virtual ~FastAPDGICP() override { gorio_apd_destroy(handle_); }
   FastAPDGICP(const FastAPDGICP&) = delete;
@@ -89,6 +97,7 @@ public:
 
   virtual void swapSourceAndTarget() override {  // APD:89-98
     input_.swap(target_);
+    lazy_tree_->defer(target_);
     check(gorio_apd_swap_source_and_target(handle_));
     source_covs_.swap(target_covs_);
     std::swap(source_covs_fresh_, target_covs_fresh_);
@@ -101,6 +110,7 @@ public:
   }
   virtual void clearTarget() override {  // APD:107-112
     target_.reset();
+    lazy_tree_->defer(PointCloudTargetConstPtr());
     target_covs_.clear();
     target_covs_fresh_ = false;
     check(gorio_apd_clear_target(handle_));
@@ -116,6 +126,7 @@ public:
   virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) override {  // APD:127-135
     if (target_ == cloud) return;
     pcl::Registration<PointSource, PointTarget, Scalar>::setInputTarget(cloud);
+    lazy_tree_->defer(cloud);
     upload(cloud->points.data(), static_cast<int>(cloud->size()), sizeof(PointTarget), false);
     target_covs_.clear();
     target_covs_fresh_ = false;
@@ -185,6 +196,7 @@ public:
     if (n > 0) check(gorio_apd_get_target_points(handle_, out->points[0].data, &out->points[0].normal_x, n, static_cast<int>(sizeof(PointTarget))));
     for (auto& p : out->points) p.data[3] = 1.0f;
     pcl::Registration<PointSource, PointTarget, Scalar>::setInputTarget(out);  // bookkeeping only: the device already holds it
+    lazy_tree_->defer(out);
     target_covs_.clear();
     target_covs_fresh_ = false;
     return out;
@@ -193,6 +205,7 @@ public:
   // device -- its points, search index and covariances -- instead of uploading and indexing a private copy.
   void setInputTargetShared(FastAPDGICP& owner) {
     pcl::Registration<PointSource, PointTarget, Scalar>::setInputTarget(owner.target_);
+    lazy_tree_->defer(owner.target_);
     check(gorio_apd_set_target_shared(handle_, owner.handle_));
     target_covs_.clear();
     target_covs_fresh_ = false;
@@ -315,6 +328,36 @@ private:
   }
 
 protected:
+  // pcl::search::KdTree whose index is built on FIRST USE instead of at every setInputTarget (see the constructor): the registration
+  // itself never searches it
+  class LazyTargetTree : public pcl::search::KdTree<PointTarget> {
+    using Base = pcl::search::KdTree<PointTarget>;
+
+  public:
+    void defer(const PointCloudTargetConstPtr& cloud) {
+      pending_ = cloud;
+      dirty_ = true;
+    }
+    int nearestKSearch(const PointTarget& point, int k, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances) const override {
+      build();
+      return Base::nearestKSearch(point, k, k_indices, k_sqr_distances);
+    }
+    int radiusSearch(const PointTarget& point, double radius, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances, unsigned int max_nn = 0) const override {
+      build();
+      return Base::radiusSearch(point, radius, k_indices, k_sqr_distances, max_nn);
+    }
+
+  private:
+    void build() const {
+      if (!dirty_) return;
+      dirty_ = false;
+      if (pending_) const_cast<LazyTargetTree*>(this)->Base::setInputCloud(pending_);
+    }
+    mutable PointCloudTargetConstPtr pending_;
+    mutable bool dirty_ = false;
+  };
+  LazyTargetTree* lazy_tree_ = nullptr;
+
   int num_threads_;
   int k_correspondences_;
   RegularizationMethod regularization_method_;

@@ -79,5 +79,12 @@ int main(int argc, char** argv) {
       prev_trans = Eigen::Matrix4f::Identity();
     }
   }
+  // The CPU kd-tree of pcl::Registration (rebuilt by initCompute() for every new target in a stock PCL registration) is built by the
+  // drop-in only when a caller really searches it, as the inlier loop of scan_matching_odometry_nodelet.cpp:679-689 does.
+  const int builds_before = pcl::search::compat_tree_builds();
+  std::vector<int> k_indices;
+  std::vector<float> k_sq_dists;
+  registration->getSearchMethodTarget()->nearestKSearch(frames[n_frames - 1]->points[0], 1, k_indices, k_sq_dists);
+  std::printf("{\"kdtree_builds_during_sequence\": %d, \"kdtree_builds_after_use\": %d, \"nn_found\": %d}\n", builds_before, pcl::search::compat_tree_builds(), (int)k_indices.size());
   return 0;
 }

@@ -105,8 +105,12 @@ int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const go
  * two objects are handed the same cloud pointer): h's target becomes THE SAME device-resident cloud as owner's current target --
  * points, covariances and search index exist once per GPU however many handles register against them (BASELINE config C5: 512 scan
  * pairs against one 1 M-point map: one upload, one index build and one k-NN pass instead of 512).  Both handles must live on one
- * device.  Results are identical to giving h a private copy.  The link is by value of the moment: a later setInputTarget / clearTarget
- * on either handle detaches that handle only.  gorio_apd_set_target_covariances on a shared target is seen by every sharer. */
+ * device.  Results are identical to giving h a private copy PROVIDED every sharer estimates covariances with the same k_correspondences
+ * and regularization (the reference estimates them per object with its own settings, APD:149-154; here the shared cloud carries one set):
+ * sharing with, or aligning / linearizing on, a handle whose two parameters differ from the ones the shared covariances were estimated with
+ * fails with GORIO_ERR_INVALID (covariances supplied through gorio_apd_set_target_covariances carry no parameters and suit every
+ * sharer).  The link is by value of the moment: a later setInputTarget / clearTarget on either handle detaches that handle only.
+ * gorio_apd_set_target_covariances on a shared target is seen by every sharer. */
 int gorio_apd_set_target_shared(gorio_apd_t* h, gorio_apd_t* owner);
 
 /*
@@ -186,7 +190,9 @@ int gorio_apd_transform_source(gorio_apd_t* h, const float T[16], float* xyz_out
  * (PCL compares the squared distance with max_range), DBL_MAX when no point qualifies.  When inlier_fraction != NULL it also
  * receives the inlier fraction of publish_scan_matching_status (scan_matching_odometry_nodelet.cpp:677-689): the share of source
  * points whose squared NN distance is < inlier_dist * inlier_dist.  The nodelet hard-codes max_correspondence_dist = 0.5 m there
- * (SMO:677); pass inlier_dist <= 0 to get exactly that.  Neither statistic depends on corr_dist_threshold. */
+ * (SMO:677); pass inlier_dist <= 0 to get exactly that.  Neither statistic depends on corr_dist_threshold.  A handle that searches only
+ * its rank's share of the source (gorio_apd_comm_init / gorio_apd_debug_set_shard with more than one rank) returns GORIO_ERR_STATE: score
+ * the pose on an unsharded handle. */
 int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range, double inlier_dist, double* score, double* inlier_fraction);
 
 /*
@@ -210,6 +216,13 @@ int gorio_apd_comm_destroy(gorio_apd_t* h);
  * return this rank's partial sums (a test adds them up itself; two such handles can live on one GPU, which two RCCL ranks cannot).
  * world_size = 1 switches it off. */
 int gorio_apd_debug_set_shard(gorio_apd_t* h, int world_size, int rank);
+/* Test hooks of the two schedule optimisations of a Gauss-Newton align, so that a regression can be localised (both default to on; neither
+ * changes a result):
+ *   fuse_step   != 0: the optimiser step of LSQ:107-123 runs in the LAST workgroup of the linearisation launch (a fence-free hand-over
+ *                     validated on gfx950); 0: it runs as its own launch after the linearisation.
+ *   plan_search != 0: from the third correspondence search of an align on, query waves that were slow in the second one are cut into
+ *                     parts and dispatched heaviest first; 0: every search uses the natural schedule. */
+int gorio_apd_debug_set_schedule(gorio_apd_t* h, int fuse_step, int plan_search);
 
 /* seconds spent inside device kernels of the last align / align_batch, by stage (HIP events on the launch stream):
  * [0] k-NN + covariance estimation, [1] correspondence search, [2] linearize, [3] LM/GN solve + error trials, [4] search-index build

@@ -1205,7 +1205,10 @@ int apdo_dbscan_labels(const float* xyz, int n, double eps, int min_pts, int min
         sq++;
         continue;
       }
-      const double r_exp = (APDO_NORM(c) - 1) / 100 + eps; /* DBS:65-67 */
+      /* DBS:65-67: (std::sqrt(float expression) - 1) / 100 is evaluated in FLOAT (float - int, float / int); only the sum with the
+       * double eps_ is double.  (The seed radius above is different: DBS:36-39 first stores the float root in a double.) */
+      const float ef = ((float)APDO_NORM(c) - 1.0f) / 100.0f;
+      const double r_exp = (double)ef + eps;
       APDO_RADIUS_SEARCH(c, r_exp, cnt);
       if (cnt >= min_pts)
         for (int j = 0; j < cnt; j++)

@@ -533,3 +533,58 @@ def test_batch_validation(gpu, gorio):
         gorio.align_batch([a, a])  # the same handle twice
     c = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0, cl_weight_points=1200)
     assert len(gorio.align_batch([a, c])) == 2  # cl_weight_points is per handle
+
+
+@pytest.mark.gpu
+def test_shared_target_refuses_other_covariance_parameters(gpu, gorio):
+    """A shared target carries ONE set of covariances: a sharer whose k_correspondences / regularization differ from the ones they were
+    estimated with is refused (the reference estimates covariances per object with its own settings, APD:149-154) -- at share time when the
+    owner's covariances already exist, at align time when the parameters change afterwards; covariances supplied by the caller suit everyone."""
+    sx, sl, tx, tl, _ = synth.scan_pair(3000, 3200, seed=91)
+    kw = dict(corr_dist_threshold=2.0, search=1, transformation_epsilon=0.05)
+    owner = gorio.ApdGicp(**kw)
+    owner.setInputTarget(tx, tl)
+    owner.setInputSource(sx, sl)
+    ro = owner.align()  # estimates the target covariances with k = 20, PLANE
+    other = gorio.ApdGicp(k_correspondences=10, **kw)
+    with pytest.raises(gorio.GorioError):
+        other.setInputTargetShared(owner)
+    same = gorio.ApdGicp(**kw)
+    same.setInputTargetShared(owner)
+    same.setInputSource(sx, sl)
+    assert np.array_equal(same.align()["T"], ro["T"])
+    same.set_params(k_correspondences=12)
+    with pytest.raises(gorio.GorioError):
+        same.align()
+    same.setInputTarget(tx, tl)  # a target of its own: estimated with k = 12
+    assert np.isfinite(same.align()["T"]).all()
+    owner.setTargetCovariances(owner.getTargetCovariances())  # supplied covariances carry no parameters
+    other.setInputTargetShared(owner)
+    other.setInputSource(sx, sl)
+    assert np.isfinite(other.align()["T"]).all()
+
+
+@pytest.mark.gpu
+def test_schedule_optimisations_do_not_change_results(gpu, gorio):
+    """A Gauss-Newton batch with unequal source sizes (one not a multiple of 256, one of 16 384 points) gives bit for bit the same poses,
+    Hessians and counters with (i) the optimiser step fused into the linearisation launch (fence-free hand-over to the last workgroup,
+    apd_kernels.hip) or run as its own launch, and (ii) the planned schedule of the pruned search (slow query waves cut into parts, heaviest
+    first) or the natural one -- the hooks of gorio_apd_debug_set_schedule exist so that a regression of either can be localised."""
+    sizes = [(16384, 16384), (5000, 5200), (4097, 6000), (2300, 2100)]
+    pairs = [synth.scan_pair(n, m, seed=300 + q) for q, (n, m) in enumerate(sizes)]
+    kw = dict(corr_dist_threshold=2.0, search=1, max_iterations=12, optimizer=0, rotation_epsilon=0.0, transformation_epsilon=0.0)
+    out = {}
+    for fuse in (True, False):
+        for plan in (True, False):
+            objs = []
+            for sx, sl, tx, tl, _ in pairs:
+                g = make(gorio, sx, sl, tx, tl, **kw)
+                g.debugSetSchedule(fuse_step=fuse, plan_search=plan)
+                objs.append(g)
+            out[(fuse, plan)] = gorio.align_batch(objs)
+    ref = out[(True, True)]
+    assert all(r["n_linearize"] == 12 for r in ref)
+    for key, res in out.items():
+        for a, b in zip(ref, res):
+            assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["H"], b["H"]), key
+            assert a["n_linearize"] == b["n_linearize"] and a["nr_iterations"] == b["nr_iterations"] and a["converged"] == b["converged"], key

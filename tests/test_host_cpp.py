@@ -51,6 +51,8 @@ def test_nodelet_call_sequence_matches_python_binding(gpu, gorio, tmp_path, pose
     r = subprocess.run([DRIVER, path], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    tree = lines.pop()  # pcl::Registration's CPU kd-tree: never built by the aligns, built once when a caller searches it
+    assert tree["kdtree_builds_during_sequence"] == 0 and tree["kdtree_builds_after_use"] == 1 and tree["nn_found"] == 1
     assert len(lines) == len(frames) - 1
     # replay the same sequence through the ctypes binding (itself parity-tested against the oracle)
     g = gorio.ApdGicp(corr_dist_threshold=2.0, transformation_epsilon=0.1, max_iterations=64)

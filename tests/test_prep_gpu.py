@@ -35,8 +35,45 @@ def test_oracle_dbscan_properties(oracle_apd):
     assert nc2 < nc
 
 
+def _float_radius_case(eps=0.9):
+    """A cloud whose clustering depends on HOW the expansion radius of DBSCAN_simple.h:65-67 is evaluated: (std::sqrt(float) - 1) / 100 in
+    float and only `+ eps_` in double (the reference) against the whole expression in double.  Returns (xyz, index of the probe point,
+    whether the reference's arithmetic claims it).  A blob of 30 points sits behind the expanded point c = (N, 0, 0); the probe t = (N, y, 0)
+    lies at a float squared distance y * y equal to the SMALLER of the two candidate squared radii (they differ by one ulp), so exactly
+    the evaluation with the larger radius claims it (the search is `d < r2`); the seed radius of DBS:36-39 never reaches it."""
+    f32 = np.float32
+    for k in range(2000):
+        N = f32(7.0) + f32(k) * f32(0.00390625)
+        ef = f32(f32(N - f32(1.0)) / f32(100.0))
+        r_f = float(ef) + eps
+        r_d = (float(N) - 1.0) / 100.0 + eps
+        r2f, r2d = f32(r_f * r_f), f32(r_d * r_d)
+        if r2f == r2d:
+            continue
+        target = min(r2f, r2d)
+        y = f32(np.sqrt(float(target)))
+        for dy in (0, 1, -1, 2, -2):
+            yy = np.nextafter(y, f32(np.inf if dy > 0 else -np.inf)) if abs(dy) == 1 else y
+            if abs(dy) == 2:
+                yy = np.nextafter(np.nextafter(y, f32(np.inf if dy > 0 else -np.inf)), f32(np.inf if dy > 0 else -np.inf))
+            if f32(yy * yy) == target:
+                rng = np.random.default_rng(12)
+                blob = np.stack([np.full(30, float(N)) + rng.uniform(-0.05, 0.05, 30), rng.uniform(-0.30, -0.15, 30), rng.uniform(-0.05, 0.05, 30)], axis=1)
+                xyz = np.concatenate([blob, [[float(N), 0.0, 0.0]], [[float(N), float(yy), 0.0]]]).astype(np.float32)
+                return xyz, len(xyz) - 1, bool(r2f > r2d)
+    raise AssertionError("no norm with differing float / double radii found")
+
+
+def test_oracle_dbscan_expansion_radius_is_float(oracle_apd):
+    """DBS:65-67 evaluates (sqrt - 1) / 100 in float: the probe point is claimed exactly when the float evaluation says so."""
+    xyz, probe, claimed = _float_radius_case()
+    lab, nc = oracle_apd.dbscan_labels(xyz)
+    assert nc == 1 and np.all(lab[:-1] == 1)
+    assert (lab[probe] == 1) == claimed
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["blobs", "blobs2", "radar4k", "radar16k", "tiny"])
+@pytest.mark.parametrize("case", ["blobs", "blobs2", "radar4k", "radar16k", "tiny", "float_radius"])
 def test_dbscan_labels_match_oracle(gpu, gorio, oracle_apd, case):
     if case == "blobs":
         xyz = _blobs(2)
@@ -46,6 +83,8 @@ def test_dbscan_labels_match_oracle(gpu, gorio, oracle_apd, case):
         xyz, _ = synth.radar_scan(4000, seed=610)
     elif case == "radar16k":
         xyz, _ = synth.radar_scan(16384, seed=611)
+    elif case == "float_radius":
+        xyz = _float_radius_case()[0]
     else:
         xyz = _blobs(4, n_blobs=1, per=25, noise=5)
     lab_o, nc_o = oracle_apd.dbscan_labels(xyz)

@@ -163,6 +163,9 @@ def test_library_side_sharding_partitions_the_source(gpu, gorio, search):
     assert all((c >= 0).sum() > 500 for c in corr)  # a real three-way split
     H, b, e = sum(p[1] for p in parts), sum(p[2] for p in parts), sum(p[0] for p in parts)
     assert np.abs(H - H1).max() / np.abs(H1).max() < 1e-13 and np.abs(b - b1).max() / np.abs(b1).max() < 1e-12 and abs(e - e1) / e1 < 1e-13
+    with pytest.raises(gorio.GorioError):  # a rank's handle sees only its share of the source: no fitness score from it
+        ranks[1].getFitnessScore(np.eye(4, dtype=np.float32))
+    assert np.isfinite(one.getFitnessScore(np.eye(4, dtype=np.float32))[0])
 
     class Ranks:
         def linearize(self, T_):
