@@ -46,7 +46,47 @@ def main():
         out[name] = dict(seed=424243, vel_hz=hz, diag={k: (float(v) if not isinstance(v, int) else v) for k, v in d.items()},
                          **{k: np.asarray(v).tolist() for k, v in m.items()})
     json.dump(out, open(os.path.join(HERE, "ugpm_c2_windows.json"), "w"), indent=1)
+    make_prep_golden(synth, apd, ugpm)
     print("golden fixtures written to", HERE)
+
+
+def prep_inputs(synth):
+    """Seeded inputs of the preprocessing / submap / LPM fixtures (shared with tests/test_golden.py, which regenerates them)."""
+    rng = np.random.default_rng(424244)
+    scan, _ = synth.radar_scan(3000, seed=424244)
+    # REVE targets: x y z intensity doppler, a moving platform with some movers and weak returns (test_prep_gpu._radar_targets)
+    txyz, _ = synth.radar_scan(1500, seed=424245)
+    r = np.linalg.norm(txyz, axis=1, keepdims=True)
+    dop = -(txyz / r) @ np.array([4.1, 0.4, -0.05]) + rng.normal(0, 0.05, 1500)
+    dop[:80] += rng.uniform(-4, 4, 80)
+    targets = np.concatenate([txyz, rng.uniform(-5, 30, 1500)[:, None], dop[:, None]], axis=1).astype(np.float32)
+    samples = rng.integers(0, 1000, (3, 5)).astype(np.uint32)
+    # submap: four keyframes moved into the newest frame
+    frames, rel = [], []
+    odoms = [synth.gt_transform([0.6 * k, 0.05 * k, 0.01 * k], [0.1 * k, -0.05 * k, 1.2 * k]) for k in range(5)]
+    for k in range(4):
+        xyz, lab = synth.radar_scan(900 + 31 * k, seed=424250 + k, sensor_pose=odoms[k])
+        frames.append((xyz, lab))
+        rel.append(np.linalg.inv(odoms[4]) @ odoms[k])
+    win = synth.imu_window(seed=424246, vel_hz=20.0)
+    q = [win["start_t"], win["start_t"] + 0.35, win["end_t"]]
+    return dict(scan=scan, targets=targets, samples=samples, frames=frames, rel=rel, win=win, q=q, lpm_kw=dict(gyr_bias=[0.002, -0.001, 0.003], vel_bias=[0.02, -0.01, 0.0]))
+
+
+def make_prep_golden(synth, apd, ugpm):
+    """Oracle outputs of the rows SURVEY 8f added (preprocessing, submap assembly) and of the LPM output type (a8), on small seeded inputs:
+    nothing else guards those restatements against silent drift."""
+    d = prep_inputs(synth)
+    lab, nc = apd.dbscan_labels(d["scan"])
+    keep = apd.radius_outlier_mask(d["scan"], 2.0, 2)
+    reve = apd.reve_estimate(d["targets"], d["samples"])
+    xs, ls = apd.submap_assemble(d["frames"], d["rel"], 0.4)
+    lpm, _ = ugpm.preintegrate(d["win"], infer_t=d["q"], type=0, **d["lpm_kw"])
+    np.savez_compressed(os.path.join(HERE, "prep_submap_lpm.npz"), dbscan_labels=lab, dbscan_clusters=nc, outlier_keep=keep,
+                        reve_v=reve["v_r"], reve_sigma=reve["sigma_v_r"], reve_inlier=reve["inlier"], reve_n_valid=reve["n_valid"], reve_success=reve["success"],
+                        submap_xyz=xs, submap_label=ls,
+                        lpm_delta_R=np.stack([m["delta_R"] for m in lpm]), lpm_delta_p=np.stack([m["delta_p"] for m in lpm]), lpm_cov=np.stack([m["cov"] for m in lpm]),
+                        lpm_dt=np.array([m["dt"] for m in lpm]))
 
 
 if __name__ == "__main__":

@@ -64,3 +64,57 @@ def test_gpu_matches_ugpm_golden(gpu, gorio):
         rot = np.linalg.norm(Rot.from_matrix(np.array(g["delta_R"]).T @ m["delta_R"]).as_rotvec())
         assert rot < 1e-4 and np.linalg.norm(m["delta_p"] - np.array(g["delta_p"])) < 1e-4
         assert np.allclose(m["cov"], g["cov"], rtol=1e-3, atol=1e-3 * np.abs(g["cov"]).max())
+
+
+# ---------------------------------------------------------------- preprocessing (f3), submap assembly (f4), LPM output type (a8)
+
+def _prep_golden():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return np.load(os.path.join(GOLD, "prep_submap_lpm.npz")), mg.prep_inputs(synth)
+
+
+def test_oracle_reproduces_prep_submap_lpm_golden(oracle_apd):
+    """The restatements of DBSCAN_simple.h, pcl::RadiusOutlierRemoval, the REVE estimator, the submap assembly and the LPM integrator still
+    give the frozen answers (labels, masks, voxel membership: exact; floating-point results: to rounding)."""
+    import oracle
+    from oracle import ugpm
+
+    oracle.build()
+    g, d = _prep_golden()
+    lab, nc = oracle_apd.dbscan_labels(d["scan"])
+    assert nc == int(g["dbscan_clusters"]) and np.array_equal(lab, g["dbscan_labels"])
+    assert np.array_equal(oracle_apd.radius_outlier_mask(d["scan"], 2.0, 2), g["outlier_keep"])
+    reve = oracle_apd.reve_estimate(d["targets"], d["samples"])
+    assert reve["success"] == bool(g["reve_success"]) and reve["n_valid"] == int(g["reve_n_valid"]) and np.array_equal(reve["inlier"], g["reve_inlier"])
+    assert np.allclose(reve["v_r"], g["reve_v"], rtol=1e-12) and np.allclose(reve["sigma_v_r"], g["reve_sigma"], rtol=1e-10)
+    xs, ls = oracle_apd.submap_assemble(d["frames"], d["rel"], 0.4)
+    assert np.array_equal(xs, g["submap_xyz"]) and np.array_equal(ls, g["submap_label"])
+    lpm, _ = ugpm.preintegrate(d["win"], infer_t=d["q"], type=0, **d["lpm_kw"])
+    for k, m in enumerate(lpm):
+        assert np.allclose(m["delta_R"], g["lpm_delta_R"][k], atol=1e-13) and np.allclose(m["delta_p"], g["lpm_delta_p"][k], atol=1e-13)
+        assert np.allclose(m["cov"], g["lpm_cov"][k], rtol=1e-10, atol=1e-18) and m["dt"] == pytest.approx(float(g["lpm_dt"][k]))
+
+
+@pytest.mark.gpu
+def test_gpu_matches_prep_submap_lpm_golden(gpu, gorio):
+    """The HIP path against the same frozen answers, without running the oracle."""
+    g, d = _prep_golden()
+    lab, nc = gorio.prep.dbscan_labels(d["scan"])
+    assert nc == int(g["dbscan_clusters"]) and np.array_equal(lab, g["dbscan_labels"])
+    assert np.array_equal(gorio.prep.radius_outlier_mask(d["scan"], 2.0, 2), g["outlier_keep"])
+    reve = gorio.prep.ego_velocity(d["targets"], d["samples"])
+    assert reve["success"] == bool(g["reve_success"]) and reve["n_valid"] == int(g["reve_n_valid"]) and np.array_equal(reve["inlier"], g["reve_inlier"])
+    assert np.allclose(reve["v_r"], g["reve_v"], rtol=1e-10, atol=1e-12) and np.allclose(reve["sigma_v_r"], g["reve_sigma"], rtol=1e-9, atol=1e-14)
+    a = gorio.ApdGicp(corr_dist_threshold=2.0)
+    n = a.setInputTargetSubmap(d["frames"], d["rel"], voxel_leaf=0.4)
+    xg, lg = a.getTargetPoints()
+    assert n == g["submap_xyz"].shape[0] and np.array_equal(xg, g["submap_xyz"]) and np.array_equal(lg, g["submap_label"])
+    lpm = gorio.ugpm_preint_batch([d["win"]], infer_t=[d["q"]], type=gorio.ugpm.LPM, **d["lpm_kw"])[0]
+    for k, m in enumerate(lpm):
+        rot = np.linalg.norm(Rot.from_matrix(g["lpm_delta_R"][k].T @ m["delta_R"]).as_rotvec())
+        assert rot < 1e-10 and np.linalg.norm(m["delta_p"] - g["lpm_delta_p"][k]) < 1e-10
+        assert np.allclose(m["cov"], g["lpm_cov"][k], rtol=1e-8, atol=1e-9 * np.abs(g["lpm_cov"][k]).max())
