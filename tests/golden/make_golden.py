@@ -58,7 +58,7 @@ def prep_inputs(synth):
     txyz, _ = synth.radar_scan(1500, seed=424245)
     r = np.linalg.norm(txyz, axis=1, keepdims=True)
     dop = -(txyz / r) @ np.array([4.1, 0.4, -0.05]) + rng.normal(0, 0.05, 1500)
-    dop[:80] += rng.uniform(-4, 4, 80)
+    dop[:40] += rng.uniform(-4, 4, 40)
     targets = np.concatenate([txyz, rng.uniform(-5, 30, 1500)[:, None], dop[:, None]], axis=1).astype(np.float32)
     samples = rng.integers(0, 1000, (3, 5)).astype(np.uint32)
     # submap: four keyframes moved into the newest frame
