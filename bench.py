@@ -62,6 +62,13 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL) in production; gloo only to rehearse the N > 1 path on one GPU")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="rehearsal only: put every rank on this device instead of LOCAL_RANK")
     ap.add_argument("--cpu-sample-pairs", type=int, default=1)
+    ap.add_argument("--coreg-points", type=int, default=262144, help="N > 1 only: source points of the sharded-source co-registration that follows the timed batch")
+    ap.add_argument("--coreg-map-points", type=int, default=1000000)
+    ap.add_argument("--coreg-only", action="store_true", help="N > 1: skip the batch workload and run only the RCCL co-registration (tests)")
+    ap.add_argument("--latency", action="store_true",
+                    help="instead of the throughput workload: ONE pair at a time through the host-memory entry points the C++ class uses (48-byte PointXYZINormal "
+                         "stride, PCIe included), shipped LM tolerances, median over --latency-reps aligns, for 5k x 5k, 16k x 16k and 16k x 100k")
+    ap.add_argument("--latency-reps", type=int, default=100)
     return ap.parse_args()
 
 
@@ -70,7 +77,8 @@ def spawn_ranks(args):
     return the worst exit code.  Rank 0 inherits stdout, so the one JSON line comes out of this process' stdout."""
     import torch
 
-    ndev = torch.cuda.device_count()  # does not initialise the GPU runtime
+    ndev = torch.cuda.device_count()  # may touch the HIP runtime (ROCm builds without amdsmi fall back to hipGetDeviceCount): from here on this
+    # process only SPAWNS children and waits for them -- it must never replace itself with another program (exec)
     if args.all_ranks_on_device < 0 and ndev < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, found {ndev}; refusing to run fewer ranks and report them as {args.gpus}\n")
         return 2
@@ -134,6 +142,23 @@ def main():
 
     gorio = importlib.import_module("go-rio_amd")
     synth = gorio.synth
+    if args.latency:
+        if rank == 0:
+            print(json.dumps(latency_mode(args, gorio, local_rank)), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        sys.exit(0)
+    if args.coreg_only:
+        if dist is None:
+            sys.stderr.write("bench.py: --coreg-only needs --gpus N with N > 1\n")
+            sys.exit(2)
+        out = guarded(lambda: coregistration(args, gorio, dist, torch, rank, world, local_rank, dev, red_dev), torch, local_rank, 300.0)
+        if rank == 0:
+            print(json.dumps({"metric": "sharded-source co-registration (RCCL all-reduce of the 6x6 normal equations)", "n_gpus": world, "coreg": out}), flush=True)
+        if out.get("timed_out"):
+            os._exit(3)
+        dist.destroy_process_group()
+        sys.exit(0 if out.get("ok", False) else 3)
     GN = 0
     n = args.points
     params = dict(corr_dist_threshold=2.0, max_iterations=args.iters, optimizer=GN, rotation_epsilon=0.0, transformation_epsilon=0.0,
@@ -276,6 +301,7 @@ def main():
         units, wins = int(cnt[0].item()), int(cnt[1].item())
 
     stage_s, stage_n = objs[0].getStageTimes()
+    resident_shape = [dict(n=r["n"], m=r["m"]) for r in resident]
     timed_T = [r["T"].copy() for r in last["apd"]]
     timed_rec = None if windows is None else last["ugpm"].copy()
 
@@ -292,9 +318,24 @@ def main():
         for o in objs:
             o.set_params(search=1)
 
+    coreg = None
+    coreg_hung = False
+    if dist is not None and args.workload == "c4" and args.all_ranks_on_device >= 0:
+        coreg = {"skipped": "rehearsal with every rank on one device: RCCL cannot place two ranks of a communicator on one GPU", "ok": True}
+    elif dist is not None and args.workload == "c4":
+        # BASELINE configs[4] / SURVEY 8(e) row 2: ONE large co-registration, source sharded over the ranks, one ncclAllReduce of the 28
+        # normal-equation sums per linearisation -- after (and outside) the timed weak-scaling batch.  It runs under a watchdog: a
+        # collective that never completes must not take the throughput line with it.
+        coreg = guarded(lambda: coregistration(args, gorio, dist, torch, rank, world, local_rank, dev, red_dev), torch, local_rank, 240.0)
+        coreg_hung = bool(coreg.get("timed_out"))
+
     rc = 0
     if rank == 0:
-        out = report(args, world, n_pairs, n, m, resident, units, wins, dt, stage_s, stage_n, dict(ugpm_stage), dict(ugpm_count), dict(phase), brute)
+        out = report(args, world, n_pairs, n, m, resident_shape, units, wins, dt, stage_s, stage_n, dict(ugpm_stage), dict(ugpm_count), dict(phase), brute)
+        if coreg is not None:
+            out["coreg"] = coreg
+            if not coreg.get("ok", False):
+                sys.stderr.write("bench.py: the RCCL co-registration did NOT pass its checks (the throughput line is unaffected): " + json.dumps(coreg) + "\n")
         if map_setup_s is not None:
             out["map_setup_ms"] = 1e3 * map_setup_s  # upload + search index + k-NN covariances of the shared map, once per GPU
         check = None
@@ -310,22 +351,204 @@ def main():
             print(json.dumps(out), flush=True)
         else:
             sys.stderr.write("bench.py: the timed path disagrees with the CPU oracle, no throughput line is printed: " + json.dumps(check) + "\n")
+    if coreg_hung:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(rc)  # a collective is stuck on this rank's GPU stream: leave without the teardown that would wait for it
     if dist is not None:
         dist.destroy_process_group()
     sys.exit(rc)
 
 
+def guarded(fn, torch, local_rank, timeout_s):
+    """Run fn on a worker thread and give up after timeout_s: returns fn's dict, or {"ok": False, "timed_out": True} / the exception text."""
+    import threading
+
+    box = {}
+
+    def work():
+        try:
+            torch.cuda.set_device(local_rank)
+            box["out"] = fn()
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON line
+            box["out"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return {"ok": False, "timed_out": True, "error": f"no result after {timeout_s:.0f} s"}
+    return box["out"]
+
+
+# ------------------------------------------------------------------------------------------- RCCL co-registration (N > 1)
+
+def coregistration(args, gorio, dist, torch, rank, world, local_rank, dev, red_dev):
+    """One --coreg-points scan against one --coreg-map-points map, the SOURCE sharded over the ranks behind the C ABI
+    (gorio_apd_comm_init): every rank searches and linearises its contiguous share, one in-place ncclAllReduce(28 doubles) per
+    linearisation follows on the launch stream, and every rank runs the identical 6x6 solve -- so the poses must agree bit for bit
+    without a broadcast.  Rank 0 also runs the same align unsharded.  Returns the evidence (RCCL's own rank count, all-reduce count,
+    pose agreement) and the rate."""
+    synth = gorio.synth
+    n, m = args.coreg_points, args.coreg_map_points
+    n_scans = max(6, m // 16384)
+    tx, tl = synth.local_map(m, seed=synth.BASE_SEED + 77, n_scans=n_scans)  # the same map on every rank (replicated, SURVEY 8e)
+    pose = np.eye(4)
+    pose[0, 3] = 0.8 * (n_scans // 2)
+    sx, sl = synth.radar_scan(n, seed=synth.BASE_SEED + 99, sensor_pose=pose)
+    guess = pose.astype(np.float32)
+    uid = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+    if rank == 0:
+        uid = torch.frombuffer(bytearray(gorio.ApdGicp.commUniqueId()), dtype=torch.uint8).to(red_dev)
+    dist.broadcast(uid, src=0)
+    uid_bytes = bytes(uid.cpu().numpy().tobytes())
+    kw = dict(device=local_rank, corr_dist_threshold=2.0, max_iterations=args.iters, optimizer=0, rotation_epsilon=0.0, transformation_epsilon=0.0, search=1)
+    g = gorio.ApdGicp(**kw)
+    g.commInit(world, rank, uid_bytes)
+    g.setInputTarget(tx, tl)
+    g.setInputSource(sx, sl)
+    g.align(guess)  # warm-up: search indices and covariances (every rank estimates them for the whole clouds: setup, not the path)
+    reps = 3
+    dist.barrier()
+    torch.cuda.synchronize()
+    _, _, c0 = g.commInfo()
+    t0 = time.perf_counter()
+    lin = 0
+    for _ in range(reps):
+        r = g.align(guess)
+        lin += r["n_linearize"]
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    w_seen, r_seen, c1 = g.commInfo()
+    mine = torch.from_numpy(np.ascontiguousarray(r["T"], np.float32).view(np.uint32).astype(np.int64).reshape(16)).to(red_dev)
+    allT = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allT, mine)
+    seen = torch.tensor([w_seen], dtype=torch.int64, device=red_dev)
+    dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+    g.commDestroy()
+    out = {"source_points": n, "map_points": m, "iterations_per_align": args.iters, "aligns_timed": reps, "linearisations_per_s": lin / float(tt.item()),
+           "ms_per_align": 1e3 * float(tt.item()) / reps, "allreduce_count": int(c1 - c0), "allreduce_per_linearisation": (c1 - c0) / max(lin, 1),
+           "ranks_seen_by_rccl": int(seen.item()), "world": world,
+           "pose_identical_on_every_rank": bool(all(torch.equal(a, allT[0]) for a in allT))}
+    if rank == 0:
+        one = gorio.ApdGicp(**kw)
+        one.setInputTarget(tx, tl)
+        one.setInputSource(sx, sl)
+        ru = one.align(guess)
+        out["max_abs_diff_vs_unsharded"] = float(np.abs(ru["T"].astype(np.float64) - r["T"].astype(np.float64)).max())
+        t1 = time.perf_counter()
+        one.align(guess)
+        out["unsharded_ms_per_align"] = 1e3 * (time.perf_counter() - t1)
+        out["ok"] = bool(out["pose_identical_on_every_rank"] and out["ranks_seen_by_rccl"] == world and out["allreduce_count"] >= lin and out["max_abs_diff_vs_unsharded"] < 1e-6)
+    else:
+        out["ok"] = True  # the verdict is rank 0's (every rank's evidence reached it through the collectives above)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------ single-pair latency
+
+def latency_mode(args, gorio, device):
+    """What the odometry nodelet sees (scan_matching_odometry_nodelet.cpp:464-468 times one align; fast_apdgicp/src/align.cpp:51-104 is
+    the reference's own harness: clear -> setInputTarget -> setInputSource -> align): ONE pair, clouds handed over as HOST arrays of
+    pcl::PointXYZINormal (48-byte stride, so the AoS gather and the PCIe copies are inside the timed call), the optimiser and tolerances the
+    launch files ship (Levenberg-Marquardt, trans-eps 0.1, rot-eps 2e-3, <= 64 iterations), nothing reused between aligns.  The oracle's
+    time for the same call sequence on the host cores stands beside it."""
+    import oracle
+    from oracle import apd as oa
+
+    oracle.build()
+    synth = gorio.synth
+    shapes = [("C1 5000 x 5000", 5000, 5000), ("16384 x 16384", 16384, 16384), ("C3 16384 x 100000 (local map)", 16384, 100000)]
+    res = []
+
+    def pcl_points(xyz, lab):
+        p = np.zeros((xyz.shape[0], 12), np.float32)
+        p[:, :3] = xyz
+        p[:, 3] = 1.0
+        p[:, 4] = lab
+        return p
+
+    for name, n, m in shapes:
+        if m <= 20000:
+            sx, sl, tx, tl, _ = synth.scan_pair(n, m, seed=synth.BASE_SEED + 11)
+        else:
+            sx, sl = synth.radar_scan(n, seed=synth.BASE_SEED + 12)
+            tx, tl = synth.local_map(m, seed=synth.BASE_SEED + 13)
+        ps, pt = pcl_points(sx, sl), pcl_points(tx, tl)
+        g = gorio.ApdGicp(device=device, corr_dist_threshold=2.0, max_iterations=64, optimizer=1, rotation_epsilon=2e-3, transformation_epsilon=0.1, search=1)
+        t_set, t_align, t_all, lins = [], [], [], []
+        for rep in range(args.latency_reps + 3):
+            g.clearSource()
+            g.clearTarget()
+            t0 = time.perf_counter()
+            g.setInputTargetPcl(pt)
+            g.setInputSourcePcl(ps)
+            t1 = time.perf_counter()
+            r = g.align()
+            t2 = time.perf_counter()
+            if rep >= 3:
+                t_set.append(t1 - t0)
+                t_align.append(t2 - t1)
+                t_all.append(t2 - t0)
+                lins.append(r["n_linearize"])
+        # the same call sequence on the CPU restatement (exact kd-tree search, OpenMP on the granted cores)
+        p = oa.launch_params(search=1)
+        p.num_threads = usable_cores()
+        to = []
+        for _ in range(3 if m <= 20000 else 2):
+            t0 = time.perf_counter()
+            cs, ct = oa.calculate_covariances(sx, p), oa.calculate_covariances(tx, p)
+            ro = oa.align(np.eye(4), sx, sl, tx, tl, cs, ct, p)
+            to.append(time.perf_counter() - t0)
+        d = np.linalg.inv(ro["T"].astype(float)) @ r["T"].astype(float)
+        res.append({"shape": name, "median_ms": 1e3 * float(np.median(t_all)), "p90_ms": 1e3 * float(np.percentile(t_all, 90)), "set_inputs_ms": 1e3 * float(np.median(t_set)),
+                    "align_ms": 1e3 * float(np.median(t_align)), "linearisations_per_align": float(np.mean(lins)), "converged": bool(r["converged"]),
+                    "linearisations_per_s": float(np.mean(lins)) / float(np.median(t_all)),
+                    "cpu_oracle_ms": 1e3 * float(np.median(to)), "cpu_cores": usable_cores(), "oracle_linearisations": int(ro["n_linearize"]),
+                    "pose_diff_vs_oracle_m": float(np.linalg.norm(d[:3, 3]))})
+    return {"metric": "APD-GICP single-pair align latency (host clouds in, pose out)", "unit": "ms", "higher_is_better": False, "n_gpus": 1, "reps": args.latency_reps,
+            "data": "synthetic", "dtype": "f32 search / f64 accumulate",
+            "config": {"workload": "one pair per call through gorio_apd_set_target / _set_source (48-byte PointXYZINormal stride) + gorio_apd_align; LM, trans-eps 0.1, rot-eps 2e-3; "
+                                   "clearTarget / clearSource before every call (nothing reused)"},
+            "value": res[1]["median_ms"], "latency": res}
+
+
 # ------------------------------------------------------------------------------------------------------------- reporting
+
+def source_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources the counters in profiles/kernel_counters.json were collected from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "go-rio_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
 
 def load_counters():
     """profiles/kernel_counters.json: EXECUTED work per launch of every hot kernel on this workload (rocprofv3 --pmc passes summarised
-    by tools/pmc_summary.py: SQ instruction counts, busy cycles, TCC fetch / write bytes).  The counts are a property of the workload
-    (deterministic kernels on seeded inputs), the durations they are divided by are measured live in this run."""
+    by tools/pmc_summary.py: SQ instruction counts, busy cycles, TCC fetch / write bytes; distance evaluations of the pruned search
+    from a -DGORIO_STATS build, tools/search_work.py).  The counts are a property of the workload (deterministic kernels on seeded
+    inputs), the durations they are divided by are measured live in this run.  The file records the hash of the kernel sources it
+    was collected from: when the sources have changed since, the counters are DROPPED (every frac = null) instead of being
+    divided by the time of kernels they no longer describe."""
     p = os.path.join(ROOT, "profiles", "kernel_counters.json")
     try:
-        return json.load(open(p))
+        doc = json.load(open(p))
     except Exception:
         return {}
+    have, want = doc.get("_source_sha16"), source_sha16()
+    if have != want:
+        sys.stderr.write(f"bench.py: profiles/kernel_counters.json was collected from kernel sources {have}, the tree now holds {want}: "
+                         "STALE counters dropped, roofline fractions are null until tools/r03/pmc.sh is re-run\n")
+        return {"_stale": True, "kernels": {}}
+    return doc
 
 
 def kernel_entry(counters, kernel, workload):
@@ -337,7 +560,7 @@ def kernel_entry(counters, kernel, workload):
     if len(es) == 1:
         return es[0]
     out = {}
-    for key in ("valu_issue_slots", "SQ_INSTS_VALU", "hbm_bytes", "mfma_flops", "fetch_bytes", "write_bytes"):
+    for key in ("valu_issue_slots", "SQ_INSTS_VALU", "hbm_bytes", "mfma_flops", "fetch_bytes", "write_bytes", "valu_fast_instructions", "valu_slow_instructions"):
         if all(key in e for e in es):
             out[key] = sum(e[key] for e in es)
     return out
@@ -356,6 +579,14 @@ def valu_roofline(kernel, entry, avg_s, extra_note=""):
             r["frac"] = r["achieved"] / PEAK_FP32_TFLOPS
             r["valu_instructions_per_launch"] = entry.get("SQ_INSTS_VALU")
             r["valu_busy_under_profiler"] = entry.get("valu_busy")
+            if entry.get("valu_slow_instructions") is not None and entry.get("SQ_INSTS_VALU"):
+                r["slow_instruction_share"] = entry["valu_slow_instructions"] / entry["SQ_INSTS_VALU"]  # half-rate instructions / all VALU instructions
+        if entry.get("distance_evaluations"):
+            # how EFFICIENT, not just how busy: the distance evaluations the exact search really performs (32 per (query, tile) item;
+            # counted by a -DGORIO_STATS build, tools/search_work.py) x 8 flop (3 sub, 3 mul, 2 add) / live time, against the FP32 peak
+            r["useful_tflops"] = entry["distance_evaluations"] * 8.0 / avg_s / 1e12
+            r["useful_frac"] = r["useful_tflops"] / PEAK_FP32_TFLOPS
+            r["distance_evaluations_per_launch"] = entry["distance_evaluations"]
         hb = entry.get("hbm_bytes")
         if hb is not None:
             r["traffic"] = hb
@@ -406,6 +637,8 @@ def report(args, world, n_pairs, n, m, resident, units, wins, dt, stage_s, stage
         kernels[k] = (mfma_roofline if k.startswith("ata_kernel") else valu_roofline)(k, e, avg(s, c))
         kernels[k].pop("note", None)
         kernels[k]["ms_per_step"] = 1e3 * s / steps
+    if counters.get("_stale"):
+        roof["note"] = "STALE: profiles/kernel_counters.json was collected from other kernel sources; " + roof.get("note", "")
     out = {
         "metric": "APD-GICP GN iters/sec on 16k-pt scans + GP-preint windows/sec",
         "value": units / dt,

@@ -51,7 +51,7 @@ APD_SYMBOLS = [
     "gorio_apd_get_target_covariances", "gorio_apd_calculate_covariances", "gorio_apd_get_knn_indices", "gorio_apd_align",
     "gorio_apd_align_batch", "gorio_apd_linearize", "gorio_apd_compute_error", "gorio_apd_get_correspondences",
     "gorio_apd_get_mahalanobis", "gorio_apd_transform_source", "gorio_apd_fitness_score", "gorio_apd_set_profiling",
-    "gorio_apd_get_stage_times", "gorio_apd_set_target_shared", "gorio_comm_get_unique_id", "gorio_apd_comm_init", "gorio_apd_comm_destroy", "gorio_apd_debug_set_shard", "gorio_apd_debug_set_schedule", "gorio_apd_set_target_submap", "gorio_apd_get_target_points",
+    "gorio_apd_get_stage_times", "gorio_apd_set_target_shared", "gorio_comm_get_unique_id", "gorio_apd_comm_init", "gorio_apd_comm_destroy", "gorio_apd_comm_info", "gorio_apd_debug_set_shard", "gorio_apd_debug_set_schedule", "gorio_apd_set_target_submap", "gorio_apd_get_target_points",
 ]
 
 _lib = None
@@ -170,6 +170,22 @@ class ApdGicp:
         _check(self._h, self._lib.gorio_apd_set_target(self._h, _p(buf, C.c_float), _p(buf[:, 3:], C.c_float) if lab is not None else None, buf.shape[0], 16))
         self._n_tgt = buf.shape[0]
 
+    def setInputSourcePcl(self, points):  # noqa: N802
+        """points: [n, 12] float32 laid out as pcl::PointXYZINormal (48 bytes: x y z 1 | normal_x normal_y normal_z 0 | intensity curvature - -):
+        exactly the pointers and stride the C++ drop-in passes (&pts[0].x, &pts[0].normal_x, sizeof(PointT)); no repacking on the way."""
+        pts = np.ascontiguousarray(points, np.float32)
+        if pts.ndim != 2 or pts.shape[1] != 12:
+            raise ValueError("points must be [n, 12] float32 (PointXYZINormal)")
+        _check(self._h, self._lib.gorio_apd_set_source(self._h, _p(pts, C.c_float), _p(pts[:, 4:], C.c_float), pts.shape[0], 48))
+        self._n_src = pts.shape[0]
+
+    def setInputTargetPcl(self, points):  # noqa: N802
+        pts = np.ascontiguousarray(points, np.float32)
+        if pts.ndim != 2 or pts.shape[1] != 12:
+            raise ValueError("points must be [n, 12] float32 (PointXYZINormal)")
+        _check(self._h, self._lib.gorio_apd_set_target(self._h, _p(pts, C.c_float), _p(pts[:, 4:], C.c_float), pts.shape[0], 48))
+        self._n_tgt = pts.shape[0]
+
     def setInputSourceDevice(self, d_x, d_y, d_z, d_label, n):  # noqa: N802 -- raw device pointers (ints)
         _check(self._h, self._lib.gorio_apd_set_source_device(self._h, C.c_void_p(d_x), C.c_void_p(d_y), C.c_void_p(d_z), C.c_void_p(d_label or 0), int(n)))
         self._n_src = int(n)
@@ -219,6 +235,11 @@ class ApdGicp:
 
     def commInit(self, world_size, rank, unique_id):  # noqa: N802
         _check(self._h, self._lib.gorio_apd_comm_init(self._h, int(world_size), int(rank), C.c_char_p(bytes(unique_id))))
+
+    def commInfo(self):  # noqa: N802 -- (world size, rank) as RCCL reports them, ncclAllReduce calls enqueued so far
+        w, r, c = C.c_int(0), C.c_int(0), C.c_longlong(0)
+        _check(self._h, self._lib.gorio_apd_comm_info(self._h, C.byref(w), C.byref(r), C.byref(c)))
+        return w.value, r.value, c.value
 
     def debugSetShard(self, world_size, rank):  # noqa: N802 -- test hook: the partition of a rank without the collectives
         _check(self._h, self._lib.gorio_apd_debug_set_shard(self._h, int(world_size), int(rank)))

@@ -115,6 +115,7 @@ struct gorio_apd {
   bool shard_only = false;  // gorio_apd_debug_set_shard: the source partition of a rank without the collectives (test hook)
   bool fuse_step = true, plan_search = true;  // gorio_apd_debug_set_schedule
   double* d_red = nullptr;  // [32] all-reduce buffer: 28 sums of a linearisation, [28] trial error, [29] scratch
+  long long allreduce_count = 0;  // ncclAllReduce calls enqueued through this handle's communicator (gorio_apd_comm_info)
   std::string err;
   // profiling
   bool profiling = false;
@@ -160,6 +161,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
@@ -176,6 +179,8 @@ Rccl& rccl() {
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.lib, "ncclCommUserRank"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
@@ -235,9 +240,9 @@ int ensure_points(gorio_apd* h, int n) {
     HIP_TRY(h, hipMalloc(&h->seed, sizeof(int) * (cap + 512)));  // indexed by sorted position < roundup(n, 512)
     h->nn_wcap = (cap + 512) / 64 + 1;
     HIP_TRY(h, hipMalloc(&h->nn_work, sizeof(unsigned int) * 2 * h->nn_wcap));
-    HIP_TRY(h, hipMalloc(&h->nn_plan, sizeof(unsigned int) * (1 + 2 * (size_t)h->nn_wcap)));
+    HIP_TRY(h, hipMalloc(&h->nn_plan, sizeof(unsigned int) * (1 + 16 * (size_t)h->nn_wcap)));
     HIP_TRY(h, hipMemsetAsync(h->nn_work, 0, sizeof(unsigned int) * 2 * h->nn_wcap, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->nn_plan, 0, sizeof(unsigned int) * (1 + 2 * (size_t)h->nn_wcap), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->nn_plan, 0, sizeof(unsigned int) * (1 + 16 * (size_t)h->nn_wcap), h->stream));
     HIP_TRY(h, hipMalloc(&h->corr, sizeof(int) * cap));
     HIP_TRY(h, hipMalloc(&h->sqd, sizeof(float) * cap));
     HIP_TRY(h, hipMalloc(&h->omega6, sizeof(double) * 6 * cap));
@@ -619,8 +624,12 @@ void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_s
     const long waves = (long)count * ((max_src_spad + 63) / 64);
     const bool no_plan = !lead->plan_search;  // gorio_apd_debug_set_schedule
     const bool planned = launch_index >= 2 && !lead->comm && !lead->shard_only && !no_plan;
+    // entries of the work list == workgroups of a planned launch: twice the query waves for a batch that fills the chip anyway, more for
+    // a few pairs (a lone 16k scan has 256 query waves: 16 parts each are 4096 workgroups), never more than 16 parts per wave
+    const int nw_max = (max_src_spad + 63) / 64;
+    const int plan_cap = std::min(16 * nw_max, std::max(2 * nw_max, 8192 / std::max(1, count)));
     if (planned) {
-      launch_pruned(dim3(2 * ((max_src_spad + 255) / 256), 1, count), lead->stream, d_desc, gate_bound(thr * thr), 2 | (launch_index & 1));
+      launch_pruned(dim3((plan_cap + 3) / 4, 1, count), lead->stream, d_desc, gate_bound(thr * thr), 2 | (launch_index & 1));
       return;
     }
     int splits = (int)(4096 / (waves > 0 ? waves : 1));  // a lone 16k scan has 256 query waves: deal the tile groups over more workgroups
@@ -632,7 +641,7 @@ void launch_nn(gorio_apd* lead, const PairDesc* d_desc, dim3 g_nn, int max_src_s
     if (max_tgt_n >= 131072 && splits < 8) splits = 8;
     while (splits & (splits - 1)) splits &= splits - 1;  // the kernel deals groups by their low bits: a power of two
     launch_pruned(dim3((max_src_spad + 255) / 256, splits, count), lead->stream, d_desc, gate_bound(thr * thr), launch_index >= 0 ? (launch_index & 1) : 0);
-    if (launch_index == 1 && !lead->comm && !lead->shard_only && !no_plan) nn_plan_kernel<<<count, 256, 0, lead->stream>>>(d_desc, 1, count);
+    if (launch_index == 1 && !lead->comm && !lead->shard_only && !no_plan) nn_plan_kernel<<<count, 256, 0, lead->stream>>>(d_desc, 1, count, plan_cap);
   } else {
     nn_search_kernel<<<g_nn, 256, 0, lead->stream>>>(d_desc);
   }
@@ -825,6 +834,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
       linearize_kernel<<<g_lin, 256, 0, lead->stream>>>(lead->d_desc, cst, 0);
       shard_reduce_partials_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red);
       NCCL_TRY(lead, R.AllReduce(lead->d_red, lead->d_red, 28, ncclDouble, ncclSum, lead->comm, lead->stream));  // THE collective: H, b, error
+      ++lead->allreduce_count;
       shard_begin_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red, cst, 0);
       int trials = 0;
       bool active = lm;
@@ -834,6 +844,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
         for (int t = 0; t < 2 && trials < lead->params.lm_max_iterations; ++t, ++trials) {
           shard_trial_error_kernel<<<1, 1024, 0, lead->stream>>>(lead->d_desc, lead->d_red + 28, cst, 0);
           NCCL_TRY(lead, R.AllReduce(lead->d_red + 28, lead->d_red + 28, 1, ncclDouble, ncclSum, lead->comm, lead->stream));
+          ++lead->allreduce_count;
           shard_trial_decide_kernel<<<1, 64, 0, lead->stream>>>(lead->d_desc, lead->d_red + 28, cst, 0);
         }
         HIP_TRY(lead, hipMemcpyAsync(&states[0], lead->d_state, sizeof(PairState), hipMemcpyDeviceToHost, lead->stream));
@@ -1560,6 +1571,20 @@ int gorio_apd_comm_init(gorio_apd_t* h, int world_size, int rank, const char id[
   h->comm_rank = rank;
   h->shard_only = false;
   h->corr_valid = false;
+  return GORIO_OK;
+}
+
+int gorio_apd_comm_info(gorio_apd_t* h, int* world_size, int* rank, long long* allreduce_count) {
+  if (!h) return GORIO_ERR_INVALID;
+  if (!h->comm) return fail(h, GORIO_ERR_STATE, "comm_info: the handle has no communicator");
+  Rccl& R = rccl();
+  int w = 0, r = 0;
+  if (!R.CommCount || !R.CommUserRank) return fail(h, GORIO_ERR_NO_DEVICE, "librccl lacks ncclCommCount / ncclCommUserRank");
+  NCCL_TRY(h, R.CommCount(h->comm, &w));  // what RCCL itself says, not what the caller passed to comm_init
+  NCCL_TRY(h, R.CommUserRank(h->comm, &r));
+  if (world_size) *world_size = w;
+  if (rank) *rank = r;
+  if (allreduce_count) *allreduce_count = h->allreduce_count;
   return GORIO_OK;
 }
 

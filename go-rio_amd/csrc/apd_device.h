@@ -87,7 +87,7 @@ struct PairDesc {
                      // pruned search of the same align); read only when state->n_linearize > 0, any in-range value is valid
   unsigned int* nn_work;  // [2][nn_wcap] cycles every query wave (64 sorted source points) spent in the pruned search: the launches of an align
                           // alternate between the two halves, so that a plan can be made from a finished launch while the next one runs
-  unsigned int* nn_plan;  // [1 + 2 nn_wcap] work plan of the next pruned searches (nn_plan_kernel): [0] = number of entries, then one entry per
+  unsigned int* nn_plan;  // [1 + 16 nn_wcap] work plan of the next pruned searches (nn_plan_kernel): [0] = number of entries, then one entry per
                           // workgroup, heaviest first: wave << 8 | part << 4 | log2(parts)
   PairState* state;
   int nn_wcap;

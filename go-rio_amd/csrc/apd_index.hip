@@ -943,9 +943,10 @@ __global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_
 // Work plan of the next pruned searches of every pair from the cycles its query waves took in a finished one (nn_work[buf]).  A launch lasts
 // as long as its slowest wave, and a few waves (far returns whose bound ball is full of target points) take 5 - 25 x the mean: each wave is
 // cut into 1, 2, 4, 8 or 16 parts (the parts share the wave's tile groups round-robin) so that no part exceeds about half the time the
-// launch would take if its work were spread perfectly, and the parts are listed heaviest first (dispatch follows the list).  The plan
-// changes the schedule, never a result.  grid: pairs, block 256.
-__global__ __launch_bounds__(256) void nn_plan_kernel(const PairDesc* __restrict__ descs, int buf, int npairs) {
+// launch would take if its work were spread perfectly, and the parts are listed heaviest first (dispatch follows the list).  The list
+// holds at most max_entries parts (the grid of the planned launches: twice the query waves for a batch, up to sixteen times for a lone
+// pair whose 256 waves cannot fill the chip otherwise).  The plan changes the schedule, never a result.  grid: pairs, block 256.
+__global__ __launch_bounds__(256) void nn_plan_kernel(const PairDesc* __restrict__ descs, int buf, int npairs, int max_entries) {
   const PairDesc& pd = descs[blockIdx.x];
   const int nw = (pd.src.idx.n + 63) / 64;
   const unsigned int* __restrict__ w = pd.nn_work + (size_t)buf * pd.nn_wcap;
@@ -969,15 +970,15 @@ __global__ __launch_bounds__(256) void nn_plan_kernel(const PairDesc* __restrict
     while (lg < max_lg && (unsigned long long)wi > (T << lg)) ++lg;
     return lg;  // log2(parts)
   };
-  for (int attempt = 0; attempt < 9; ++attempt) {  // at most 2 nw entries (the grid of a planned launch covers exactly that many)
-    if (attempt == 8) max_lg = 0;  // never reached with sane work figures: one part per wave always fits
+  for (int attempt = 0; attempt < 13; ++attempt) {  // at most max_entries (>= nw) entries: the grid of a planned launch covers exactly that many
+    if (attempt == 12) max_lg = 0;  // never reached with sane work figures: one part per wave always fits
     if (tid == 0) s_entries = 0u;
     __syncthreads();
     unsigned int mine = 0u;
     for (int i = tid; i < nw; i += 256) mine += 1u << parts_of(w[i]);
     atomicAdd(&s_entries, mine);
     __syncthreads();
-    const bool ok = s_entries <= 2u * (unsigned int)nw;
+    const bool ok = s_entries <= (unsigned int)max_entries;
     __syncthreads();
     if (ok) break;
     T *= 2ull;

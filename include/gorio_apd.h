@@ -212,6 +212,10 @@ int gorio_apd_fitness_score(gorio_apd_t* h, const float T[16], double max_range,
 int gorio_comm_get_unique_id(char id[128]);
 int gorio_apd_comm_init(gorio_apd_t* h, int world_size, int rank, const char id[128]);
 int gorio_apd_comm_destroy(gorio_apd_t* h);
+/* What RCCL reports about the handle's communicator (ncclCommCount, ncclCommUserRank) and how many ncclAllReduce calls the handle has
+ * enqueued on it since comm_init: evidence for benchmarks and tests that the collective path ran across that many ranks.  Any output
+ * pointer may be NULL.  GORIO_ERR_STATE without a communicator. */
+int gorio_apd_comm_info(gorio_apd_t* h, int* world_size, int* rank, long long* allreduce_count);
 /* Test hook: the source partition of rank `rank` of `world_size` WITHOUT a communicator -- gorio_apd_linearize / _compute_error then
  * return this rank's partial sums (a test adds them up itself; two such handles can live on one GPU, which two RCCL ranks cannot).
  * world_size = 1 switches it off. */

@@ -56,3 +56,23 @@ def test_two_ranks_rehearsal_on_one_gpu(gpu):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["pairs_per_gpu"] == 4
     assert out["value"] == pytest.approx(2 * 4 * 20 * 2 / (out["ms_per_step"] * 1e-3 * 2), rel=1e-6)  # both ranks' linearisations / max time
     assert out["check"]["ok"]
+
+
+@pytest.mark.gpu
+def test_rccl_coregistration_across_two_gpus(gpu):
+    """BASELINE configs[4] / SURVEY 8(e) row 2 on real hardware: two ranks, one GPU each, one source sharded over them behind the C ABI, one
+    ncclAllReduce per linearisation.  Skips on a one-GPU box (two RCCL ranks cannot share a device); on a node with >= 2 GPUs it checks
+    that RCCL itself reports two ranks, that the collective ran once per linearisation, that both ranks end on bit-identical poses and
+    that the pose equals the unsharded align's to 1e-6."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: two RCCL ranks cannot share one device")
+    r = _run(["--gpus", "2", "--coreg-only", "--coreg-points", "65536", "--coreg-map-points", "200000", "--iters", "10"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    c = json.loads(lines[0])["coreg"]
+    assert c["ok"] and c["ranks_seen_by_rccl"] == 2 and c["pose_identical_on_every_rank"]
+    assert c["allreduce_per_linearisation"] == 1.0 and c["allreduce_count"] == 10 * c["aligns_timed"]
+    assert c["max_abs_diff_vs_unsharded"] < 1e-6

@@ -102,7 +102,18 @@ def main():
             e["fetch_bytes"], e["write_bytes"] = fetch, c.get("WRITE_SIZE", 0.0) * 1024.0
             e["hbm_bytes"] = fetch + e["write_bytes"]
         out[f"{k}:{args.workload}"] = e
-    doc = {"_note": ("per-launch averages of rocprofv3 --pmc passes (separate passes per counter group, never combined with the trace domains), MI355X. " + args.note).strip(),
+    import hashlib
+
+    def source_sha16():
+        h = hashlib.sha256()
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "go-rio_amd", "csrc")
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h")):
+                h.update(name.encode())
+                h.update(open(os.path.join(d, name), "rb").read())
+        return h.hexdigest()[:16]
+
+    doc = {"_source_sha16": source_sha16(), "_note": ("per-launch averages of rocprofv3 --pmc passes (separate passes per counter group, never combined with the trace domains), MI355X. " + args.note).strip(),
            "kernels": out}
     if args.out:
         old = {}
@@ -111,9 +122,18 @@ def main():
                 old = json.load(open(args.out)).get("kernels", {})
             except Exception:
                 old = {}
-        for k, e in old.items():  # keep entries of other workloads
-            if not k.endswith(":" + args.workload):
-                doc["kernels"].setdefault(k, e)
+        old_doc = {}
+        try:
+            old_doc = json.load(open(args.out))
+        except Exception:
+            pass
+        if old_doc.get("_source_sha16") == doc["_source_sha16"]:  # entries of other workloads collected from the SAME sources stay
+            for k, e in old.items():
+                if not k.endswith(":" + args.workload):
+                    doc["kernels"].setdefault(k, e)
+                elif k in doc["kernels"]:
+                    for kk, vv in e.items():  # fields another tool merged in (tools/search_work.py)
+                        doc["kernels"][k].setdefault(kk, vv)
         json.dump(doc, open(args.out, "w"), indent=1, sort_keys=True)
     else:
         json.dump(doc, sys.stdout, indent=1, sort_keys=True)

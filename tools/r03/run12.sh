@@ -17,4 +17,4 @@ for f in sorted(glob.glob('gpurun_out/r03/ab12_*.json')+glob.glob('gpurun_out/r0
         d=json.load(open(f)); print(f, round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['device_ms_per_step'].items() if not k.startswith('ugpm')})
     except Exception as e: print(f, 'ERR', e)
 PY
-GORIO_AMD_LIB=$PWD/tools/variants/nn_stats.so timeout -k 10 300 python tools/nn_stats.py c4 20 2>&1 | grep -v "cycles per wave\|share"
+GORIO_AMD_LIB=$PWD/tools/variants/nn_stats.so timeout -k 10 300 python tools/search_work.py c4 20 2>&1 | grep -v "cycles per wave\|share"

@@ -21,7 +21,7 @@ for f in sorted(glob.glob('gpurun_out/r03/ab3_*.json')+glob.glob('gpurun_out/r03
         d=json.load(open(f)); print(f, round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['device_ms_per_step'].items() if not k.startswith('ugpm')})
     except Exception as e: print(f, 'ERR', e)
 PY
-GORIO_AMD_LIB=$PWD/tools/variants/nn_stats_s8w4.so timeout -k 10 300 python tools/nn_stats.py c4 20 > gpurun_out/r03/stats3_c4.txt 2>&1 || { tail -20 gpurun_out/r03/stats3_c4.txt; exit 1; }
+GORIO_AMD_LIB=$PWD/tools/variants/nn_stats_s8w4.so timeout -k 10 300 python tools/search_work.py c4 20 > gpurun_out/r03/stats3_c4.txt 2>&1 || { tail -20 gpurun_out/r03/stats3_c4.txt; exit 1; }
 cat gpurun_out/r03/stats3_c4.txt
-GORIO_AMD_LIB=$PWD/tools/variants/nn_stats_s8w4.so timeout -k 10 400 python tools/nn_stats.py c5 20 > gpurun_out/r03/stats3_c5.txt 2>&1 || { tail -20 gpurun_out/r03/stats3_c5.txt; exit 1; }
+GORIO_AMD_LIB=$PWD/tools/variants/nn_stats_s8w4.so timeout -k 10 400 python tools/search_work.py c5 20 > gpurun_out/r03/stats3_c5.txt 2>&1 || { tail -20 gpurun_out/r03/stats3_c5.txt; exit 1; }
 cat gpurun_out/r03/stats3_c5.txt
