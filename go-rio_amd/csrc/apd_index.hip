@@ -1158,8 +1158,8 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __rest
   const int lane = threadIdx.x & 63;
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
-  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
-  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
+  const float qlo[3] = {wave_fmin_u(qx), wave_fmin_u(qy), wave_fmin_u(qz)};  // DPP reductions, wave-uniform results
+  const float qhi[3] = {wave_fmax_u(qx), wave_fmax_u(qy), wave_fmax_u(qz)};
   const scalar_fp tx = as_scalar(si.sx);
   const scalar_fp ty = as_scalar(si.sy);
   const scalar_fp tz = as_scalar(si.sz);
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __rest
       hi = tb4[2 * (size_t)tl + 1];
     }
     for (int phase = (g == g0 ? 0 : 1); phase < 2; ++phase) {  // own tiles first: they fill the list with near neighbours
-      const float wb = wave_max(D[K - 1]);
+      const float wb = wave_fmax_u(D[K - 1]);
       unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) < wb);  // strictly below: an equal distance changes no distance list
       if (g == g0) {
         const int ol = own_tile - g * 64;
@@ -1191,8 +1191,8 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __rest
       while (mask) {
         const int tlane = __builtin_ctzll(mask);
         mask &= mask - 1;
-        const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
-        if (__ballot(box_bound(qx, qy, qz, bx) < D[K - 1]) == 0) continue;
+        const TileBox bx = TileBox{lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+        if (__ballot(box_bound_s(qx, qy, qz, bx) < D[K - 1]) == 0) continue;
         const int j0 = (g * 64 + tlane) * 32;
 #pragma unroll 2
         for (int gg = 0; gg < 32; gg += 8) {
@@ -1226,8 +1226,8 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
   const int lane = threadIdx.x & 63;
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
-  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
-  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
+  const float qlo[3] = {wave_fmin_u(qx), wave_fmin_u(qy), wave_fmin_u(qz)};  // DPP reductions, wave-uniform results
+  const float qhi[3] = {wave_fmax_u(qx), wave_fmax_u(qy), wave_fmax_u(qz)};
   const scalar_fp tx = as_scalar(si.sx);
   const scalar_fp ty = as_scalar(si.sy);
   const scalar_fp tz = as_scalar(si.sz);
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
   const float dk = job.kth[p];
   int cnt = 0;
   {
-    const float wb = wave_max(dk);
+    const float wb = wave_fmax_u(dk);
     for (int g = 0; g < ng; ++g) {
       const int tl = g * 64 + lane;
       float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
@@ -1251,8 +1251,8 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
       while (mask) {
         const int tlane = __builtin_ctzll(mask);
         mask &= mask - 1;
-        const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
-        if (__ballot(box_bound(qx, qy, qz, bx) <= dk) == 0) continue;
+        const TileBox bx = TileBox{lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+        if (__ballot(box_bound_s(qx, qy, qz, bx) <= dk) == 0) continue;
         const int j0 = (g * 64 + tlane) * 32;
 #pragma unroll
         for (int gg = 0; gg < 32; gg += 8) {

@@ -40,6 +40,7 @@ struct Ctx {  // per-thread, per-device cached buffers
   UgpmWin* d_wins = nullptr;
   int wins_cap = 0;
   int* d_ints = nullptr;  // per window: kWinInts ints (lmi[16], status)
+  int lm_budget[2] = {0, 0};  // iterations the two fits of the PREVIOUS batch needed: that many are enqueued before the first look at the done flags
   double* d_diag = nullptr;
   // opt.type = LPM windows (ugpm_lpm_out.hip)
   double* lpm_ws = nullptr;
@@ -628,7 +629,13 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
           }
         }
         if (!any) break;
-        if (it >= 3 && (it & 1) == 1) {  // poll the done flags every other iteration (no window of the C2 shape finishes in fewer than four)
+        // When to look at the done flags (a look drains the stream: copy, synchronise, ~30 us of idle GPU).  A finished window's kernels
+        // return at once, so iterations enqueued beyond the need cost four empty launches each, far less than a look.  The first batch of a
+        // context looks every other iteration from the fourth on (no window of the C2 shape finishes in fewer than four); later batches
+        // enqueue as many iterations as the previous batch needed before the first look -- on like data that look is the only one.
+        const int budget = c.lm_budget[problem];
+        const bool look = budget > 0 ? (it + 1 >= budget && ((it + 1 - budget) & 1) == 0) : (it >= 3 && (it & 1) == 1);
+        if (look) {
           for (Run& r : runs)
             if (r.active) UHIP(hipMemcpyAsync(flags.data() + kWinInts * (size_t)r.g0, c.d_ints + kWinInts * (size_t)r.g0, sizeof(int) * kWinInts * (size_t)r.nw, hipMemcpyDeviceToHost, r.s));
           for (Run& r : runs) {
@@ -638,6 +645,9 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
             for (int i = r.g0; i < r.g0 + r.nw; ++i) all = all && (flags[kWinInts * (size_t)i + 1] || flags[kWinInts * (size_t)i + 16] != 0);
             if (all) r.active = false;
           }
+          bool every = true;
+          for (Run& r : runs) every = every && !r.active;
+          if (every) c.lm_budget[problem] = std::max(1, it + 1);  // iterations enqueued when the last window was seen done
         }
       }
       for (size_t g = 0; g < runs.size(); ++g) {
