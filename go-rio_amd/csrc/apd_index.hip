@@ -946,7 +946,7 @@ __global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_
 // launch would take if its work were spread perfectly, and the parts are listed heaviest first (dispatch follows the list).  The list
 // holds at most max_entries parts (the grid of the planned launches: twice the query waves for a batch, up to sixteen times for a lone
 // pair whose 256 waves cannot fill the chip otherwise).  The plan changes the schedule, never a result.  grid: pairs, block 256.
-__global__ __launch_bounds__(256) void nn_plan_kernel(const PairDesc* __restrict__ descs, int buf, int npairs, int max_entries) {
+__global__ __launch_bounds__(256) void nn_plan_kernel(const PairDesc* __restrict__ descs, int buf, int npairs, int max_entries, int budget_div) {
   const PairDesc& pd = descs[blockIdx.x];
   const int nw = (pd.src.idx.n + 63) / 64;
   const unsigned int* __restrict__ w = pd.nn_work + (size_t)buf * pd.nn_wcap;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256) void nn_plan_kernel(const PairDesc* __restrict
   atomicAdd(&s_tot, loc);
   __syncthreads();
   // budget of one part: half of (all work of the batch / wave slots of the chip), assuming the pairs of a batch are alike
-  unsigned long long T = s_tot * (unsigned long long)npairs / 10240ull;
+  unsigned long long T = s_tot * (unsigned long long)npairs / (unsigned long long)budget_div;
   if (T < 4096ull) T = 4096ull;
   int max_lg = 4;
   auto parts_of = [&](unsigned int wi) -> int {
