@@ -493,7 +493,11 @@ __device__ __forceinline__ float sumsq2_f(float a, float b) {  // x^2 + y^2 in f
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void linearize_kernel(const PairDesc* __restrict__ descs, ApdConsts cst, int fuse) {
   const PairDesc& pd = descs[blockIdx.z];
   PairState* __restrict__ st = pd.state;
-  if (st->done) return;
+  // the optimiser state is constant until the LAST workgroup of the launch rewrites it (gn_step_tail, after every other workgroup has
+  // arrived): read it through the scalar cache.  Through the generic pointer these would be flat loads, whose completion the compiler
+  // can only wait for together with every other outstanding load.
+  const __attribute__((address_space(4))) PairState* sst = (const __attribute__((address_space(4))) PairState*)pd.state;
+  if (sst->done) return;
   const int n = pd.src.n;
   if (blockIdx.x * 256 >= n) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -503,7 +507,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   for (int t = 0; t < 28; ++t) acc[t] = 0.0;
 
   if (i < n) {
-    const unsigned long long key = pd.best_key[i];
+    // every load of this point is issued up front through the global address space -- the key first (the target gathers depend on
+    // it), then the source side, which does not -- and unconditionally (indices clamped): a load inside a branch makes the compiler
+    // wait for all outstanding loads at the join.
+    typedef const __attribute__((address_space(1))) unsigned long long* g_u64p;
+    typedef const __attribute__((address_space(1))) double* g_f64p;
+    typedef const __attribute__((address_space(1))) float* g_f32p;
+    const unsigned long long key = ((g_u64p)pd.best_key)[i];
+    const float ax = ((g_f32p)pd.src.x)[i], ay = ((g_f32p)pd.src.y)[i], az = ((g_f32p)pd.src.z)[i];
+    const float src_label = ((g_f32p)pd.src.label)[i];
+    const double src_geo_w = ((g_f64p)pd.src.geo_w)[i];
+    double cA[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) cA[t] = ((g_f64p)pd.src.cov6)[(size_t)i * 6 + t];
     pd.best_key[i] = ~0ull;  // re-arm for the next search
     const float d = __uint_as_float((unsigned int)(key >> 32));
     int j = (int)(unsigned int)(key & 0xffffffffu);
@@ -511,15 +527,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     pd.sqd[i] = found ? d : INFINITY;                       // APD:180
     if (!found || !((double)d < cst.thr2)) j = -1;          // APD:183
     pd.corr[i] = j;
+    const int jj = j >= 0 ? j : 0;
+    double cB[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) cB[t] = ((g_f64p)pd.tgt.cov6)[(size_t)jj * 6 + t];
+    float4 tb;  // the matched target point and its cluster label in one 16-byte gather
+    {
+      typedef float v4f_lin __attribute__((ext_vector_type(4)));
+      const v4f_lin t4 = ((const __attribute__((address_space(1))) v4f_lin*)pd.tgt.p4)[jj];
+      tb = make_float4(t4.x, t4.y, t4.z, t4.w);
+    }
     double* om = pd.omega6 + (size_t)i * 6;
     if (j >= 0) {
       // fp64 from here on is tolerance arithmetic (H, b, error agree with the host restatement to 1e-9): let the compiler fuse
       // multiply-adds in THIS block (the build is -ffp-contract=off for the float search arithmetic, which lives in functions of its own)
 #pragma clang fp contract(fast)
-      const double* __restrict__ T = st->x0;
-      const float ax = pd.src.x[i], ay = pd.src.y[i], az = pd.src.z[i];
+      double T[12];
+      float Tf[12];
+#pragma unroll
+      for (int t = 0; t < 12; ++t) {
+        T[t] = sst->x0[t];
+        Tf[t] = sst->Tf[t];
+      }
       float qx, qy, qz;
-      transform_f(st->Tf, ax, ay, az, qx, qy, qz);
+      transform_f(Tf, ax, ay, az, qx, qy, qz);
       // sensor covariance at the transformed point, APD:194-210
       const double px = (double)qx, py = (double)qy, pz = (double)qz;
       const double pxy2 = px * px + py * py;
@@ -559,8 +590,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       const double r12 = A10 * A20 + A12 * A22;
       const double r22 = A20 * A20 + A22 * A22;
       // RCR = (C_B + cov_r) + R (C_A + cov_r) R^T, APD:213-214 (3x3 block; row/col 3 of the 4x4 decouple, APD:215-218)
-      const double* cA = pd.src.cov6 + (size_t)i * 6;
-      const double* cB = pd.tgt.cov6 + (size_t)j * 6;
       const double a00 = cA[0] + r00, a01 = cA[1] + r01, a02 = cA[2] + r02, a11 = cA[3] + r11, a12 = cA[4] + r12, a22 = cA[5] + r22;
       // M = R * Asym
       const double R00 = T[0], R01 = T[1], R02 = T[2], R10 = T[4], R11 = T[5], R12 = T[6], R20 = T[8], R21 = T[9], R22 = T[10];
@@ -579,9 +608,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         om[0] = p.o00; om[1] = p.o01; om[2] = p.o02; om[3] = p.o11; om[4] = p.o12; om[5] = p.o22;
       }
 
-      const float4 tb = pd.tgt.p4[j];  // the matched target point and its cluster label in one 16-byte gather
       const double quad = residual_terms(T, ax, ay, az, tb.x, tb.y, tb.z, p);  // APD:255-263
-      const double w = 1.0 + pd.src.geo_w[i] + ((tb.w == pd.src.label[i]) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);  // APD:266-276
+      const double w = 1.0 + src_geo_w + ((tb.w == src_label) ? 1.0 / (double)(pd.cl_points > 0 ? pd.cl_points : n) : 0.0);  // APD:266-276
       acc[27] = w * quad;
 
       // J = [skew(Ta) | -I], APD:284-287.  With S = skew(Ta): H_rr = S^T O S, H_rt = -S^T O, H_tt = O, b_r = S^T O e, b_t = -O e.
