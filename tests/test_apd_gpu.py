@@ -588,3 +588,27 @@ def test_schedule_optimisations_do_not_change_results(gpu, gorio):
         for a, b in zip(ref, res):
             assert np.array_equal(a["T"], b["T"]) and np.array_equal(a["H"], b["H"]), key
             assert a["n_linearize"] == b["n_linearize"] and a["nr_iterations"] == b["nr_iterations"] and a["converged"] == b["converged"], key
+
+
+@pytest.mark.gpu
+def test_seeded_and_planned_searches_keep_ties_on_the_lowest_index(gpu, gorio):
+    """Equal distances all the way through an align: a lattice target with exact duplicates, a source half a cell off (every query
+    equidistant from four lattice points, some of them duplicated, in different tiles), eight fixed Gauss-Newton iterations -- so the
+    unseeded search, the seeded one and the planned ones (query waves cut into parts that meet in an atomic min) all see ties.  The pruned
+    search must give bit for bit what the exhaustive one gives (ties on the lowest original index), pose and correspondences included."""
+    gx, gy = np.meshgrid(np.arange(70, dtype=np.float32), np.arange(70, dtype=np.float32))
+    lattice = np.stack([gx.ravel(), gy.ravel(), 0.05 * np.sin(gx.ravel() * 0.3)], axis=1).astype(np.float32)
+    tgt = np.concatenate([lattice, lattice[::5]])  # 4900 points + 980 exact duplicates with higher indices
+    src = lattice[: 64 * 60] + np.array([0.5, 0.5, 0.0], np.float32)
+    kw = dict(corr_dist_threshold=2.0, max_iterations=8, optimizer=0, rotation_epsilon=0.0, transformation_epsilon=0.0)
+    res = {}
+    for search in (0, 1):
+        g = make(gorio, src, None, tgt, None, search=search, **kw)
+        r = g.align()
+        g.linearize(r["T"].astype(np.float64))
+        res[search] = (r, g.getCorrespondences())
+    (rb, (cb, sb)), (rp, (cp, sp)) = res[0], res[1]
+    assert rb["n_linearize"] == 8 and rp["n_linearize"] == 8
+    assert np.array_equal(rb["T"], rp["T"]) and np.array_equal(rb["H"], rp["H"])
+    assert np.array_equal(cb, cp) and np.array_equal(sb, sp)
+    assert (cp < 4900).all() and (cp >= 0).all()  # never a duplicate's (higher) index
