@@ -522,12 +522,6 @@ __device__ __forceinline__ unsigned int umin3(unsigned int a, unsigned int b, un
 struct TileBox {
   float lx, ly, lz, p0, hx, hy, hz, p1;
 };
-__device__ __forceinline__ TileBox sload_box(scalar_fp tb, int tile) {  // tile is wave-uniform: one s_load_dwordx8
-  const scalar_fp b = tb + (size_t)tile * 8;
-  TileBox r;
-  r.lx = b[0]; r.ly = b[1]; r.lz = b[2]; r.p0 = b[3]; r.hx = b[4]; r.hy = b[5]; r.hz = b[6]; r.p1 = b[7];
-  return r;
-}
 // per-lane lower bound of sqdist3(q, p) over the box: per axis max(lo - q, q - hi, 0) is |q - clamp(q)| computed without a clamp, and
 // the squares are summed in the order of sqdist3, so the value is the one box_bound() gives
 __device__ __forceinline__ float box_bound_s(float qx, float qy, float qz, const TileBox& b) {
@@ -619,7 +613,6 @@ __global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_
   // round trips to L2, 1-2 k cycles each under load): the query, its seed, the boxes of the first 64 blocks, of the super tiles of the
   // home block and of the tiles of the home group (where the wave's queries sit in the target's order: almost always the first group
   // visited).  The traversal below takes a box from these registers when the id matches and loads it otherwise.
-  const float4 kInfLo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), kInfHi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
   // (every index is clamped into its array and the condition applied to the loaded value: a load inside a branch ends the compiler's
   // tracking of outstanding loads at the join, and it then waits for ALL of them at the first use of any)
   // the seed first: the point it names is the one dependent load of this block, and the counter of outstanding loads is in order
@@ -1237,6 +1230,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
   __shared__ unsigned long long s_buf[CAP][kKnnBlock];  // keys at or below d_k, one column per lane (bank = lane: conflict free)
   const int ng = (si.n_tiles + 63) / 64;
   const float dk = job.kth[p];
+  STAT_ADD(0, 1);
   int cnt = 0;
   {
     const float wb = wave_fmax_u(dk);
@@ -1252,7 +1246,10 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
         const int tlane = __builtin_ctzll(mask);
         mask &= mask - 1;
         const TileBox bx = TileBox{lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
-        if (__ballot(box_bound_s(qx, qy, qz, bx) <= dk) == 0) continue;
+        const unsigned long long needb = __ballot(box_bound_s(qx, qy, qz, bx) <= dk);
+        if (needb == 0) continue;
+        STAT_ADD(1, 1);
+        STAT_ADD(2, __builtin_popcountll(needb));
         const int j0 = (g * 64 + tlane) * 32;
 #pragma unroll
         for (int gg = 0; gg < 32; gg += 8) {
