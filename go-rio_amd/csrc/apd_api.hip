@@ -116,6 +116,15 @@ struct gorio_apd {
   bool fuse_step = true, plan_search = true;  // gorio_apd_debug_set_schedule
   double* d_red = nullptr;  // [32] all-reduce buffer: 28 sums of a linearisation, [28] trial error, [29] scratch
   long long allreduce_count = 0;  // ncclAllReduce calls enqueued through this handle's communicator (gorio_apd_comm_info)
+  // pinned host staging of the small descriptor arrays a call uploads (index jobs, k-NN jobs, pair descriptors / states, copy jobs): a
+  // copy from pageable memory needs a stream drain before the vector it came from may die; a pinned buffer of the handle's own needs none
+  struct Pinned {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;  // recorded behind the last upload from this buffer: the next writer waits for it
+    bool pending = false;
+  };
+  Pinned pin_ijobs, pin_jobs, pin_desc, pin_states, pin_copy;
   std::string err;
   // profiling
   bool profiling = false;
@@ -153,6 +162,28 @@ int fail(gorio_apd* h, int code, const std::string& msg) {
   } while (0)
 
 int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+// Upload `bytes` of a short-lived host array through the handle's pinned staging buffer `b`: no stream drain, the caller's array may die
+// right away.  A buffer that still feeds an earlier upload is waited for first (its event), never overwritten under it.
+int upload_staged(gorio_apd* h, gorio_apd::Pinned& b, void* dst, const void* src, size_t bytes) {
+  if (b.pending) {
+    HIP_TRY(h, hipEventSynchronize(b.ev));
+    b.pending = false;
+  }
+  if (bytes > b.cap) {
+    if (b.p) hipHostFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    HIP_TRY(h, hipHostMalloc(&b.p, bytes + bytes / 2 + 256, hipHostMallocDefault));
+    b.cap = bytes + bytes / 2 + 256;
+  }
+  if (!b.ev) HIP_TRY(h, hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+  std::memcpy(b.p, src, bytes);
+  HIP_TRY(h, hipMemcpyAsync(dst, b.p, bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipEventRecord(b.ev, h->stream));
+  b.pending = true;
+  return GORIO_OK;
+}
 
 // RCCL is loaded on first use (dlopen): a process that never shards a source never needs librccl, and one that already has a copy
 // mapped (PyTorch ships its own) keeps using that copy.
@@ -470,8 +501,7 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     HIP_TRY(lead, hipMalloc(&lead->d_ijobs, sizeof(IndexJob) * nj));
     lead->ijobs_cap = nj;
   }
-  HIP_TRY(lead, hipMemcpyAsync(lead->d_ijobs, jobs.data(), sizeof(IndexJob) * nj, hipMemcpyHostToDevice, lead->stream));
-  HIP_TRY(lead, hipStreamSynchronize(lead->stream));  // pageable staging
+  if (int rc = upload_staged(lead, lead->pin_ijobs, lead->d_ijobs, jobs.data(), sizeof(IndexJob) * nj)) return rc;
   {
     StageTimer t(lead, 4);
     const IndexJob* dj = lead->d_ijobs;
@@ -569,8 +599,7 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     HIP_TRY(lead, hipMalloc(&lead->d_jobs, sizeof(KnnJob) * njobs));
     lead->jobs_cap = njobs;
   }
-  HIP_TRY(lead, hipMemcpyAsync(lead->d_jobs, jobs.data(), sizeof(KnnJob) * njobs, hipMemcpyHostToDevice, lead->stream));
-  HIP_TRY(lead, hipStreamSynchronize(lead->stream));  // jobs vector is pageable host memory
+  if (int rc = upload_staged(lead, lead->pin_jobs, lead->d_jobs, jobs.data(), sizeof(KnnJob) * njobs)) return rc;
   {
     StageTimer t(lead, 0);
     dim3 g1((max_n + 255) / 256, max_splits, njobs), g2((max_n + 255) / 256, 1, njobs);
@@ -822,11 +851,10 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     if (descs[q].nn_splits > max_splits) max_splits = descs[q].nn_splits;
     hs[q]->corr_valid = true;
   }
-  HIP_TRY(lead, hipMemcpyAsync(lead->d_desc, descs.data(), sizeof(PairDesc) * count, hipMemcpyHostToDevice, lead->stream));
-  HIP_TRY(lead, hipMemcpyAsync(lead->d_states_batch, states.data(), sizeof(PairState) * count, hipMemcpyHostToDevice, lead->stream));
+  if (int rc2 = upload_staged(lead, lead->pin_desc, lead->d_desc, descs.data(), sizeof(PairDesc) * count)) return rc2;
+  if (int rc2 = upload_staged(lead, lead->pin_states, lead->d_states_batch, states.data(), sizeof(PairState) * count)) return rc2;
   scatter_states_kernel<<<count, 64, 0, lead->stream>>>(lead->d_desc, lead->d_states_batch);
   arm_keys_kernel<<<dim3(std::min(64, (max_n + 255) / 256), count), 256, 0, lead->stream>>>(lead->d_desc);
-  HIP_TRY(lead, hipStreamSynchronize(lead->stream));
 
   const ApdConsts cst = make_consts(lead->params);
   const dim3 g_nn((max_n + 255) / 256, max_splits, count), g_lin((max_n + 255) / 256, 1, count), g_lm(count);
@@ -893,6 +921,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
       }
     }
     launched += todo_it;
+    chunk_iters = std::min(16, chunk_iters * 2);  // every look at the done flags drains the stream: 4, 8, 16, 16, ... iterations between looks
     HIP_TRY(lead, hipGetLastError());
     gather_states_kernel<<<count, 64, 0, lead->stream>>>(lead->d_desc, lead->d_states_batch);
     HIP_TRY(lead, hipMemcpyAsync(states.data(), lead->d_states_batch, sizeof(PairState) * count, hipMemcpyDeviceToHost, lead->stream));
@@ -992,6 +1021,10 @@ void gorio_apd_destroy(gorio_apd_t* h) {
   hipFree(h->best_key); hipFree(h->seed); hipFree(h->nn_work); hipFree(h->nn_plan); hipFree(h->corr); hipFree(h->sqd); hipFree(h->omega6); hipFree(h->partials);
   hipFree(h->d_state); hipFree(h->d_desc); hipFree(h->d_states_batch); hipFree(h->d_jobs); hipFree(h->d_ijobs); hipFree(h->d_fit); hipFree(h->d_copy_jobs);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
+  for (gorio_apd::Pinned* b : {&h->pin_ijobs, &h->pin_jobs, &h->pin_desc, &h->pin_states, &h->pin_copy}) {
+    if (b->p) hipHostFree(b->p);
+    if (b->ev) hipEventDestroy(b->ev);
+  }
   delete h;
 }
 
@@ -1083,8 +1116,7 @@ int gorio_apd_set_clouds_device_batch(gorio_apd_t** handles, int count, const go
     HIP_TRY(lead, hipMalloc(&lead->d_copy_jobs, bytes));
     lead->copy_jobs_cap = bytes;
   }
-  HIP_TRY(lead, hipMemcpyAsync(lead->d_copy_jobs, jobs.data(), bytes, hipMemcpyHostToDevice, lead->stream));
-  HIP_TRY(lead, hipStreamSynchronize(lead->stream));  // pageable staging vector
+  if (int rc = upload_staged(lead, lead->pin_copy, lead->d_copy_jobs, jobs.data(), bytes)) return rc;
   copy_clouds_kernel<<<dim3(std::min(16, (max_pad + 255) / 256), (unsigned)jobs.size()), 256, 0, lead->stream>>>(static_cast<const CopyJob*>(lead->d_copy_jobs));
   HIP_TRY(lead, hipGetLastError());
   return GORIO_OK;
