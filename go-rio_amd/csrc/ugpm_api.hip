@@ -581,7 +581,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       {
         Stage st(c, 1, r.s);
         ug::gram_kernel<<<dim3(6, r.nw), 256, 0, r.s>>>(dw_);
-        ug::cross_kernel<<<dim3(12, r.nw, (std::max(max_G, max_V) + ug::kCrossRows - 1) / ug::kCrossRows), 256, 0, r.s>>>(dw_);
+        ug::cross_kernel<<<dim3(12, r.nw, (std::max(max_G, max_V) + ug::kCrossRows - 1) / ug::kCrossRows), 256, sizeof(double) * ug::kCrossRows * (((max_S + 31) / 32) * 32 + 4), r.s>>>(dw_);
       }
       // State correlation at the LPM-initialised state.  The reference assembles the Jacobian synchronously (preint.h:887-937) and
       // hands J^T J, its factorisation and the inverse diagonal to a helper thread that runs beside the two ceres::Solve calls and is

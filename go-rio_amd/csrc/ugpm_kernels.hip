@@ -1272,8 +1272,11 @@ __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ 
   const double* Ki = w.Kinv + (size_t)ch * S * S;
   const double l2 = w.hyper[ch * 4 + 0], sf2 = w.hyper[ch * 4 + 1];
   const bool integral = (kind == 1 || kind == 2);
-  constexpr int LDK = 164;  // row stride of the staged kernel rows: 4 doubles past a multiple of 32 banks
-  __shared__ double ks[kCrossRows][LDK];
+  // row stride of the staged kernel rows: 4 doubles past a multiple of 32 banks that holds S columns (dynamic LDS: 25 KB at S = 66 instead of
+  // the 42 KB a stride for the largest S would take -- these workgroups share their CUs with the scan matcher's kernels)
+  const int LDK = ((S + 31) / 32) * 32 + 4;
+  extern __shared__ double ks_dyn[];
+  double* ks = ks_dyn;  // [kCrossRows][LDK]
   const int row0 = blockIdx.z * kCrossRows;
   if (row0 >= N) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1282,7 +1285,7 @@ __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ 
     for (int k = lane; k < LDK; k += 64) {
       double v = 0.0;
       if (n < N && k < S) v = integral ? se_kint(w.start_t, tt[n], w.state_t[k], l2, sf2) : se_k(tt[n], w.state_t[k], l2, sf2);
-      ks[r][k] = v;
+      ks[(size_t)r * LDK + k] = v;
     }
   }
   __syncthreads();
@@ -1296,7 +1299,7 @@ __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ 
 #pragma unroll 4
     for (int k0 = 0; k0 < S; k0 += 4) {
       const int k = k0 + lk;
-      const double av = ks[ti * 16 + lr][k];  // zero for k >= S
+      const double av = ks[(size_t)(ti * 16 + lr) * LDK + k];  // zero for k >= S
       const double bv = (k < S && j < S) ? Ki[(size_t)k * S + j] : 0.0;
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
