@@ -42,8 +42,8 @@ VALU_SLOTS_PER_S = 1024 * 2.4e9 / 2.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c5"],
                     help="c4 (default, the metric's configuration); c3: one 16k scan vs a 100k map; c5: ONE RANK'S SHARE of the 8-GPU configuration -- "
                          "--pairs scans against one shared --map-points map (map index and covariances are setup, not part of a step)")
