@@ -449,10 +449,13 @@ void resolve_stage_events(gorio_apd* h) {
 // Build the search accelerator of every listed cloud that lacks one (batched: one launch per sort stage for all clouds).
 int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*>>& clouds) {
   std::vector<std::pair<gorio_apd*, DevCloud*>> todo;
+  bool small_call = true;  // every cloud named in the call (built now or not) is a scan-sized one: kd chunks of 2048 points (kd_refine_kernel)
   {
     std::unordered_set<DevCloud*> seen;
-    for (auto& c : clouds)
+    for (auto& c : clouds) {
+      if (c.second->n > kKdSmallCloud) small_call = false;
       if (!c.second->idx_valid && seen.insert(c.second).second) todo.push_back(c);
+    }
   }
   if (todo.empty()) return GORIO_OK;
   const int nj = (int)todo.size();
@@ -514,7 +517,8 @@ int run_index_build(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
       bitonic_tile_merge_kernel<<<dim3(max_pow2 / kSortTile, nj), 1024, 0, lead->stream>>>(dj, k);
     }
     gather_sorted_kernel<<<dim3((max_spad + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
-    kd_refine_kernel<<<dim3((max_spad + kKdChunk - 1) / kKdChunk, nj), 1024, 0, lead->stream>>>(dj);
+    if (small_call) kd_refine_kernel<2048><<<dim3((max_spad + 2047) / 2048, nj), 512, 0, lead->stream>>>(dj);
+    else kd_refine_kernel<4096><<<dim3((max_spad + 4095) / 4096, nj), 1024, 0, lead->stream>>>(dj);
     box_tile_kernel<<<dim3((max_spad / 32 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
     box_super_kernel<<<dim3((max_spad / 512 + 255) / 256, nj), 256, 0, lead->stream>>>(dj);
     box_block_kernel<<<dim3((max_spad / 32768 + 64) / 64, nj), 64, 0, lead->stream>>>(dj);
@@ -816,10 +820,8 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
       if (h->tgt->cov_count != h->tgt->n && seen.insert(h->tgt.get()).second) todo.emplace_back(h, h->tgt.get());
     }
   }
-  int rc = run_covariances(lead, todo);
-  if (rc) return rc;
-
-  if (lead->params.search == GORIO_SEARCH_PRUNED) {
+  int rc = GORIO_OK;
+  if (lead->params.search == GORIO_SEARCH_PRUNED) {  // the search indices first, for ALL clouds of the batch in one call: the kd chunk size is chosen by the whole set (run_index_build)
     std::vector<std::pair<gorio_apd*, DevCloud*>> all;
     for (int q = 0; q < count; ++q) {
       all.emplace_back(hs[q], hs[q]->src.get());
@@ -828,6 +830,9 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     rc = run_index_build(lead, all);
     if (rc) return rc;
   }
+  rc = run_covariances(lead, todo);
+  if (rc) return rc;
+
   rc = ensure_batch(lead, count);
   if (rc) return rc;
   long total_src_waves = 0;
@@ -1361,7 +1366,15 @@ int gorio_apd_calculate_covariances(gorio_apd_t* h) {
       todo.emplace_back(h, c);
     }
   }
-  int rc = run_covariances(h, todo);
+  int rc = GORIO_OK;
+  if (p.search == GORIO_SEARCH_PRUNED && !todo.empty()) {  // indices of both clouds in one call (kd chunk size by the pair, run_index_build)
+    std::vector<std::pair<gorio_apd*, DevCloud*>> both;
+    for (DevCloud* c : {h->src.get(), h->tgt.get()})
+      if (c->present) both.emplace_back(h, c);
+    rc = run_index_build(h, both);
+    if (rc) return rc;
+  }
+  rc = run_covariances(h, todo);
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   resolve_stage_events(h);

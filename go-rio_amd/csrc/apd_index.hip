@@ -198,8 +198,16 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const IndexJob* __re
 // Per level (segment sizes 4096 .. 64): segment bounding boxes (wave reductions + LDS atomics), widest axis, bitonic sort of
 // every segment by that coordinate, payload permutation.  Padding points (1e30) are the largest on every axis and therefore stay
 // at the tail of the chunk.  grid: (chunks over max n_spad, jobs), block 1024.
-constexpr int kKdChunk = 4096;
-__global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restrict__ jobs) {
+// Chunk size (a multiple of 1024, at most 4096: the index inside a chunk takes 12 key bits) by the clouds of the call: 2048 points when
+// every cloud named in the call has at most kKdSmallCloud points, 4096 otherwise.  Measured in round 3: 16 k-point scans against each other
+// build faster with the smaller chunk (0.71 -> 0.60 ms per C4 batch: 512-thread workgroups, one sort level less) AND search faster (20
+// searches 1.99 -> 1.90 ms, k-NN 1.66 -> 1.59 ms, a lone 5 k x 5 k align 0.95 -> 0.79 ms); scans that meet a big map search it faster
+// when THEY are ordered with 4096-point chunks too (64 scans x 1 M-point map: 20 searches 10.2 vs 10.9 ms), and the map's own tiles are
+// worse with small chunks (11.2 ms with 1024).
+constexpr int kKdSmallCloud = 65536;
+template <int kKdChunk>
+__global__ __launch_bounds__(kKdChunk / 4) void kd_refine_kernel(const IndexJob* __restrict__ jobs) {
+  constexpr int kKdThreads = kKdChunk / 4;  // four points, two compare-exchange pairs per thread and stage
   const IndexJob& jb = jobs[blockIdx.y];
   const int base = blockIdx.x * kKdChunk;
   if (base >= jb.idx.n_spad) return;
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restr
   __shared__ unsigned long long keys[kKdChunk];
   __shared__ unsigned int sb[64][6];  // per segment: ordered-uint min x,y,z / max x,y,z
   const int tid = threadIdx.x, lane = tid & 63;
-  for (int e = tid; e < kKdChunk; e += 1024) {
+  for (int e = tid; e < kKdChunk; e += kKdThreads) {
     const int p = base + e;
     const bool in = p < jb.idx.n_spad;
     px[e] = in ? jb.idx.sx[p] : 1e30f;
@@ -219,10 +227,10 @@ __global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restr
   __syncthreads();
   for (int seg = kKdChunk; seg >= 64; seg >>= 1) {
     const int nseg = kKdChunk / seg;
-    for (int q = tid; q < nseg * 6; q += 1024) sb[q / 6][q % 6] = (q % 6) < 3 ? 0xffffffffu : 0u;
+    for (int q = tid; q < nseg * 6; q += kKdThreads) sb[q / 6][q % 6] = (q % 6) < 3 ? 0xffffffffu : 0u;
     __syncthreads();
     for (int r = 0; r < 4; ++r) {
-      const int e = tid + 1024 * r;
+      const int e = tid + kKdThreads * r;
       const bool valid = po[e] != 0x7fffffff;
       const float v[3] = {px[e], py[e], pz[e]};
 #pragma unroll
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restr
     }
     __syncthreads();
     for (int r = 0; r < 4; ++r) {
-      const int e = tid + 1024 * r;
+      const int e = tid + kKdThreads * r;
       const unsigned int* b = sb[e / seg];
       int axis = 0;
       float best = -1.0f;
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restr
       for (; lj >= 8; --lj) {
         const int j = 1 << lj;
         for (int r = 0; r < 2; ++r) {
-          const int t = tid + 1024 * r;
+          const int t = tid + kKdThreads * r;
           const int lo = ((t >> lj) << (lj + 1)) | (t & (j - 1)), hi = lo + j;
           const bool up = (k == seg) || ((lo & k) == 0);
           unsigned long long a = keys[lo], b = keys[hi];
@@ -299,17 +307,17 @@ __global__ __launch_bounds__(1024) void kd_refine_kernel(const IndexJob* __restr
     float nx[4], ny[4], nz[4];
     int no[4];
     for (int r = 0; r < 4; ++r) {
-      const int src = (int)(keys[tid + 1024 * r] & 4095ull);
+      const int src = (int)(keys[tid + kKdThreads * r] & 4095ull);
       nx[r] = px[src]; ny[r] = py[src]; nz[r] = pz[src]; no[r] = po[src];
     }
     __syncthreads();
     for (int r = 0; r < 4; ++r) {
-      const int e = tid + 1024 * r;
+      const int e = tid + kKdThreads * r;
       px[e] = nx[r]; py[e] = ny[r]; pz[e] = nz[r]; po[e] = no[r];
     }
     __syncthreads();
   }
-  for (int e = tid; e < kKdChunk; e += 1024) {
+  for (int e = tid; e < kKdChunk; e += kKdThreads) {
     const int p = base + e;
     if (p < jb.idx.n_spad) {
       jb.idx.sx[p] = px[e];
