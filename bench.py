@@ -324,10 +324,10 @@ def main():
         coreg = {"skipped": "rehearsal with every rank on one device: RCCL cannot place two ranks of a communicator on one GPU", "ok": True}
     elif dist is not None and args.workload == "c4":
         # BASELINE configs[4] / SURVEY 8(e) row 2: ONE large co-registration, source sharded over the ranks, one ncclAllReduce of the 28
-        # normal-equation sums per linearisation -- after (and outside) the timed weak-scaling batch.  It runs under a watchdog: a
-        # collective that never completes must not take the throughput line with it.
-        coreg = guarded(lambda: coregistration(args, gorio, dist, torch, rank, world, local_rank, dev, red_dev), torch, local_rank, 240.0)
-        coreg_hung = bool(coreg.get("timed_out"))
+        # normal-equation sums per linearisation -- after (and outside) the timed weak-scaling batch.  Every rank runs it in a CHILD
+        # process (`bench.py --coreg-only`, its own rendezvous): a collective that never completes, or a crash inside it, must not take
+        # the throughput line with it.
+        coreg = coreg_in_children(args, dist, torch, rank, world, local_rank, red_dev)
 
     rc = 0
     if rank == 0:
@@ -358,6 +358,46 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     sys.exit(rc)
+
+
+def coreg_in_children(args, dist, torch, rank, world, local_rank, red_dev):
+    """Every rank starts `bench.py --gpus N --coreg-only` as a child on its own GPU (fresh rendezvous port agreed through the parent's
+    process group), waits for it with a timeout and kills it when it does not finish; rank 0 returns the child's `coreg` record (or why
+    there is none).  The parents only spawn and wait: nothing here replaces a running program."""
+    port = torch.zeros(1, dtype=torch.int64, device=red_dev)
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast(port, src=0)
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port.item())),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--coreg-only", "--coreg-points", str(args.coreg_points),
+           "--coreg-map-points", str(args.coreg_map_points), "--iters", str(args.iters)]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+    out, err, timed_out = "", "", False
+    try:
+        out, err = child.communicate(timeout=420.0)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        child.kill()
+        try:
+            out, err = child.communicate(timeout=10.0)
+        except Exception:  # noqa: BLE001
+            pass
+    rec = None
+    if rank == 0:
+        for ln in (out or "").splitlines():
+            if ln.startswith("{"):
+                try:
+                    rec = json.loads(ln).get("coreg")
+                except Exception:  # noqa: BLE001
+                    rec = None
+        if rec is None:
+            rec = {"ok": False, "timed_out": timed_out, "exit_code": child.returncode, "error": ((err or "")[-600:] or "the co-registration child printed no record")}
+        rec["ran_in"] = "child processes (one per rank), after the timed region"
+    dist.barrier()
+    return rec
 
 
 def guarded(fn, torch, local_rank, timeout_s):
