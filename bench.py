@@ -320,7 +320,7 @@ def main():
 
     coreg = None
     coreg_hung = False
-    if dist is not None and args.workload == "c4" and args.all_ranks_on_device >= 0:
+    if dist is not None and args.workload == "c4" and args.all_ranks_on_device >= 0 and not os.environ.get("GORIO_BENCH_FORCE_COREG"):
         coreg = {"skipped": "rehearsal with every rank on one device: RCCL cannot place two ranks of a communicator on one GPU", "ok": True}
     elif dist is not None and args.workload == "c4":
         # BASELINE configs[4] / SURVEY 8(e) row 2: ONE large co-registration, source sharded over the ranks, one ncclAllReduce of the 28
@@ -373,7 +373,9 @@ def coreg_in_children(args, dist, torch, rank, world, local_rank, red_dev):
     env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port.item())),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--coreg-only", "--coreg-points", str(args.coreg_points),
-           "--coreg-map-points", str(args.coreg_map_points), "--iters", str(args.iters)]
+           "--coreg-map-points", str(args.coreg_map_points), "--iters", str(args.iters), "--dist-backend", args.dist_backend]
+    if args.all_ranks_on_device >= 0:  # rehearsal of the plumbing only: RCCL itself refuses two ranks on one device
+        cmd += ["--all-ranks-on-device", str(args.all_ranks_on_device)]
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
     out, err, timed_out = "", "", False
     try:
