@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run comparison with the CPU oracle (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="run the GP windows after the scan matching instead of beside it")
+    ap.add_argument("--ugpm-four-launch", action="store_true", help="experiment: the rotation fit as four launches per iteration (gorio_ugpm_debug_set_schedule(0))")
     ap.add_argument("--no-exhaustive", action="store_true", help="skip the extra untimed step that times the exhaustive search kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl (= RCCL) in production; gloo only to rehearse the N > 1 path on one GPU")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="rehearsal only: put every rank on this device instead of LOCAL_RANK")
@@ -141,6 +142,8 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     gorio = importlib.import_module("go-rio_amd")
+    if args.ugpm_four_launch:
+        importlib.import_module("go-rio_amd.ugpm").ugpm_debug_set_schedule(False)
     synth = gorio.synth
     if args.latency:
         if rank == 0:

@@ -12,6 +12,7 @@
 #include <limits>
 #include <memory>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/gorio_ugpm.h"
@@ -53,6 +54,7 @@ struct Ctx {  // per-thread, per-device cached buffers
   std::vector<int> ev_stage;
 };
 thread_local Ctx g_ctx;
+std::atomic<int> g_speculative_rot{1};  // gorio_ugpm_debug_set_schedule
 
 int ufail(int code, const std::string& msg) {
   g_err = msg;
@@ -218,6 +220,8 @@ void gorio_ugpm_default_window(gorio_ugpm_window* w) {
 
 const char* gorio_ugpm_last_error(void) { return g_err.c_str(); }
 
+void gorio_ugpm_debug_set_schedule(int speculative_rot) { g_speculative_rot.store(speculative_rot ? 1 : 0); }
+
 int gorio_ugpm_get_stage_times(double seconds[8], int counts[8]) {
   for (int i = 0; i < 8; ++i) {
     if (seconds) seconds[i] = g_stage_s[i];
@@ -268,6 +272,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   }
   for (int i = 0; i < 8; ++i) { g_stage_s[i] = 0; g_stage_n[i] = 0; }
   const bool trace = std::getenv("GORIO_UGPM_TRACE") != nullptr;
+  const bool lmtrace = std::getenv("GORIO_UGPM_LMTRACE") != nullptr;
   auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tt0 = tnow();
   double tt1 = 0, tt2 = 0, tt3 = 0;
@@ -551,7 +556,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       if (g > 0) UHIP(hipStreamWaitEvent(runs[g].s, c.ev_up, 0));
     }
     // J^T J launches: one workgroup per (row slice, tile group, window), see ata_kernel
-    auto launch_ata = [&](const Run& r, int which) {
+    auto launch_ata = [&](const Run& r, int which, int decide = 0) {
       hipStream_t sq = which == 2 ? r.s2 : r.s;
       Stage st_ata(c, which == 2 ? 6 : 5, sq);
       const int n = (which == 2 ? 6 : 3) * max_S, T = (n + 15) / 16, ntile = T * (T + 1) / 2;
@@ -563,12 +568,12 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       // LDS as small as the staging needs (53 KB at n = 198): the scan matcher's kernels share the CUs with these workgroups
       auto lds = [&](int kc) { return sizeof(double) * 2 * kc * (npad + 1); };
       if (which == 2) {
-        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng);
-        else if (npad <= 512) ug::ata_kernel<8, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng);
-        else ug::ata_kernel<16, 8, kAtaTilesCorr><<<grid, 512, lds(8), sq>>>(dw_, which, r.nw, ng);
+        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng, decide);
+        else if (npad <= 512) ug::ata_kernel<8, 16, kAtaTilesCorr><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng, decide);
+        else ug::ata_kernel<16, 8, kAtaTilesCorr><<<grid, 512, lds(8), sq>>>(dw_, which, r.nw, ng, decide);
       } else {
-        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng);
-        else ug::ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng);  // n = 3S <= 480
+        if (npad <= 256) ug::ata_kernel<4, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng, decide);
+        else ug::ata_kernel<8, 16, kAtaTilesLm><<<grid, 512, lds(16), sq>>>(dw_, which, r.nw, ng, decide);  // n = 3S <= 480
       }
     };
     for (const Run& r : runs) {
@@ -601,6 +606,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
       UHIP(hipEventRecord(r.ev_corr, r.s2));
     }
     std::vector<int> flags(kWinInts * (size_t)nw);
+    const bool speculative = g_speculative_rot.load() != 0;
     for (int problem = 0; problem < 2; ++problem) {  // ceres::Solve #1 (rotation) and #2 (velocity), preint.h:943-967
       std::vector<std::unique_ptr<Stage>> st_lm;
       for (Run& r : runs) {
@@ -619,6 +625,13 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
           any = true;
           const UgpmWin* dw_ = c.d_wins + r.g0;
           ug::lm_step_kernel<<<dim3(r.nw, problem == 1 ? kVelBlocks : 1), 512, 0, r.s>>>(dw_);
+          if (problem == 0 && speculative) {
+            // three launches per iteration: the candidate residual AND the Jacobian at the candidate in one evaluation, the
+            // acceptance test inside the J^T J launch (rot_eval_kernel mode 3, ata_kernel decide)
+            ug::rot_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 3);
+            launch_ata(r, problem, 1);
+            continue;
+          }
           if (problem == 0) ug::rot_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 0);
           else ug::vel_eval_kernel<<<dim3(r.nw, kEvalSplit), 256, 0, r.s>>>(dw_, 0);
           if (problem == 0) {
@@ -629,8 +642,17 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
           }
         }
         if (!any) break;
+        if (lmtrace) {  // GORIO_UGPM_LMTRACE: the solver's control words of window 0 after every iteration (a debugging aid: drains the stream)
+          double lc[16];
+          int li[16];
+          UHIP(hipStreamSynchronize(runs[0].s));
+          UHIP(hipMemcpy(lc, dw[0].lmc, sizeof(lc), hipMemcpyDeviceToHost));
+          UHIP(hipMemcpy(li, dw[0].lmi, sizeof(li), hipMemcpyDeviceToHost));
+          std::fprintf(stderr, "[ugpm lm] problem %d it %d: iter %d done %d term %d succ %d cost %.17g cost_new %.17g radius %.6g mcc %.17g step_norm2 %.6g x_norm %.17g initial %.17g\n", problem, it,
+                       li[0], li[1], li[5], li[6], lc[0], lc[1], lc[2], lc[8], lc[11], lc[4], lc[7]);
+        }
         // When to look at the done flags (a look drains the stream: copy, synchronise, ~30 us of idle GPU).  A finished window's kernels
-        // return at once, so iterations enqueued beyond the need cost four empty launches each, far less than a look.  The first batch of a
+        // return at once, so iterations enqueued beyond the need cost three empty launches each, far less than a look.  The first batch of a
         // context looks every other iteration from the fourth on (no window of the C2 shape finishes in fewer than four); later batches
         // enqueue as many iterations as the previous batch needed before the first look -- on like data that look is the only one.
         const int budget = c.lm_budget[problem];
@@ -647,7 +669,15 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
           }
           bool every = true;
           for (Run& r : runs) every = every && !r.active;
-          if (every) c.lm_budget[problem] = std::max(1, it + 1);  // iterations enqueued when the last window was seen done
+          if (every) {  // iterations the slowest window really needed: its step count, plus the step kernel that noticed a termination of its own (gradient, iteration cap, radius)
+            int need = 1;
+            for (int i = 0; i < nw; ++i) {
+              const int* f = flags.data() + kWinInts * (size_t)i;
+              if (f[16] != 0) continue;
+              need = std::max(need, f[0] + (f[5] >= 3 ? 1 : 0));
+            }
+            c.lm_budget[problem] = std::min(need, it + 1);
+          }
         }
       }
       for (size_t g = 0; g < runs.size(); ++g) {

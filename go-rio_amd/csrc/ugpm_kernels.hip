@@ -1435,7 +1435,9 @@ __device__ int lm_decide_block(const UgpmWin& w, int m, int n, bool commit, doub
     return 0;
   }
   double c = 0.0;
-  for (int k = threadIdx.x; k < m; k += blockDim.x) c += w.res_new[k] * w.res_new[k];
+  const int nacc = min((int)blockDim.x, 256);  // 256 accumulators in every caller: the sum does not depend on the caller's block size
+  if ((int)threadIdx.x < nacc)
+    for (int k = threadIdx.x; k < m; k += nacc) c += w.res_new[k] * w.res_new[k];
   const double cost_new = 0.5 * block_sum(c, sred);
   const double cost = w.lmc[0];
   const double cost_change = cost - cost_new;
@@ -1488,20 +1490,24 @@ __device__ void gpnorm_rows(const UgpmWin& w, int ch, const double* __restrict__
 }
 
 // Problem #1 (preint.h:872-952): unknowns x = [s_dr0 | s_dr1 | s_dr2] (3S); rows = 3 GpNorm blocks (3S) then RotCost (3G).
-// grid: (windows, splits), block 256: the workgroups of one window share its samples.  mode: 0 residual at x_new -> res_new; 1 residual + Jacobian at x -> res, Jrot; 2 as 1 and also
-// (re)writes the constant GpNorm blocks and zeroes the rest (first evaluation).
+// grid: (windows, splits), block 256: the workgroups of one window share its samples.  mode: 0 residual at x_new -> res_new; 1 (after
+// the acceptance test) residual + Jacobian at x_new -> res, Jrot; 2 as 1 at x and also (re)writes the constant GpNorm blocks and zeroes
+// the rest (first evaluation); 3 = 0 and the Jacobian rows of 1 in ONE launch, BEFORE the acceptance test: residual at x_new ->
+// res_new, Jacobian at x_new -> Jrot.  Nothing but the J^T J launch that follows reads Jrot, and that launch takes the acceptance
+// test itself (ata_kernel, decide) and leaves J^T J and g alone after a rejected step, so the speculative rows cost one write of
+// Jrot on the rare rejection and save a launch -- and the second pass over the kernel tables -- on every iteration.
 __global__ __launch_bounds__(256) void rot_eval_kernel(const UgpmWin* __restrict__ wins, int mode) {
   const UgpmWin w = load_win(wins, blockIdx.x);
   if (*w.status != 0 || w.lmi[1]) return;
   const int S = w.S, G = w.G, n = 3 * S;
   __shared__ double sred[8];
-  if (mode == 0 && blockIdx.y == 0 && threadIdx.x == 0) lm_step_bookkeeping(w);
+  if ((mode == 0 || mode == 3) && blockIdx.y == 0 && threadIdx.x == 0) lm_step_bookkeeping(w);
   if (mode == 1) {  // step acceptance (see lm_decide_block), then the Jacobian only after an accepted step -- at x_new, which is
                     // what the committing workgroup is copying into x meanwhile
     if (lm_decide_block(w, 3 * S + 3 * G, n, blockIdx.y == 0, sred) != 1) return;
   }
   const double* x = mode == 2 ? w.lmv + 5 * (size_t)n : w.lmv + 6 * (size_t)n;
-  double* res = mode == 0 ? w.res_new : w.res;
+  double* res = (mode == 0 || mode == 3) ? w.res_new : w.res;
   double* J = w.Jrot;
   const int i_lo = (int)(((long)G * blockIdx.y) / gridDim.y), i_hi = (int)(((long)G * (blockIdx.y + 1)) / gridDim.y);  // this workgroup's samples
   if (mode == 2) {  // zero the rows this workgroup owns: its GpNorm channel block and its sample rows
@@ -1776,12 +1782,13 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
 // workgroups with partial tiles, an arrival counter and an ordered reduction was measured in round 1 and dropped.)
 // grid: 1-D, ceil(units / 8) * 8 workgroups with unit = (window, group).
 // which: 0 rot problem, 1 vel problem, 2 correlation.  Dynamic LDS: 2 * KC * (npad + 1) doubles.  n <= 512 when g is formed.
+// decide (LM problems): take the step acceptance test first, see below.
 __device__ __forceinline__ int ata_npad(int n) { return ((n + 15) / 32) * 32 + 16; }  // >= round_up(n, 16); rows 32 banks apart
 
 // CMAX = 64-column groups of a staged row (npad <= 64 CMAX), KC = rows per staged chunk, TPG = output tiles per workgroup (8 waves x
 // TPG / 8 accumulators): 32 for the LM problems (n = 3S: more, shorter workgroups), 48 for the correlation (n = 6S).
 template <int CMAX, int KC, int TPG>
-__global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wins, int which, int n_windows, int groups_max) {
+__global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wins, int which, int n_windows, int groups_max, int decide) {
   const int L = blockIdx.x;
   const int xcd = L & 7, pslot = L >> 3;
   const int unit = pslot * 8 + xcd;
@@ -1798,11 +1805,23 @@ __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wi
     if (!w.correlate) return;
     m = 3 * w.G + 3 * w.V; n = 6 * w.S; A = w.Jc; C = w.Ac;
   } else {
-    if (w.lmi[1] || !w.lmi[3]) return;
+    if (w.lmi[1]) return;
     n = 3 * w.S;
     m = which == 0 ? 3 * w.S + 3 * w.G : 3 * w.V + 3 * w.S;
     A = which == 0 ? w.Jrot : w.Jvel;
     C = w.JtJ; r = w.res; g = w.lmv;
+    if (decide) {
+      // The Jacobian in A was written at the CANDIDATE point (rot_eval_kernel mode 3).  Every workgroup of the window takes the
+      // acceptance test for itself (lm_decide_block; group 0 stores the new solver state) and only an accepted step is linearised:
+      // J^T J and g keep the values of the current point otherwise.  The residual of the new point is the candidate residual.
+      __shared__ double sred[8];
+      if (lm_decide_block(w, m, n, grp == 0, sred) != 1) return;
+      r = w.res_new;
+      if (grp == 0)
+        for (int k = threadIdx.x; k < m; k += blockDim.x) w.res[k] = r[k];
+    } else if (!w.lmi[3]) {
+      return;
+    }
   }
   const int T = (n + 15) / 16, ntile = T * (T + 1) / 2;
   const int ng = (ntile + TPG - 1) / TPG;

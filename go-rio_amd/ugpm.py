@@ -13,7 +13,7 @@ from .apd import GorioError, load_library
 LPM, UGPM = 0, 1
 REC = 83
 
-UGPM_SYMBOLS = ["gorio_ugpm_default_window", "gorio_ugpm_preint_batch", "gorio_ugpm_last_error", "gorio_ugpm_get_stage_times"]
+UGPM_SYMBOLS = ["gorio_ugpm_default_window", "gorio_ugpm_preint_batch", "gorio_ugpm_last_error", "gorio_ugpm_get_stage_times", "gorio_ugpm_debug_set_schedule"]
 
 
 class UgpmWindow(C.Structure):
@@ -123,6 +123,14 @@ def ugpm_preint_batch(windows, device=0, infer_t=None, type=UGPM, state_freq=50.
     if return_diag:
         return b.results(), b.diagnostics()
     return b.results()
+
+
+def ugpm_debug_set_schedule(speculative_rot=True):
+    """gorio_ugpm_debug_set_schedule (test hook, process-wide): the rotation fit as three launches per iteration (default) or four."""
+    lib = load_library()
+    lib.gorio_ugpm_debug_set_schedule.argtypes = [C.c_int]
+    lib.gorio_ugpm_debug_set_schedule.restype = None
+    lib.gorio_ugpm_debug_set_schedule(1 if speculative_rot else 0)
 
 
 def ugpm_stage_times():

@@ -113,6 +113,11 @@ const char* gorio_ugpm_last_error(void);
  * (a part of [3]), [6] the J^T J launch of the correlation (a part of [2]), [7] reserved; and launch-set counts. Either may be NULL. */
 int gorio_ugpm_get_stage_times(double seconds[8], int counts[8]);
 
+/* Test hook, process-wide: speculative_rot = 0 runs the rotation fit (PRE:943-952) as four launches per iteration (step, candidate
+ * residual, acceptance + Jacobian, J^T J) instead of three (step, candidate residual + Jacobian, acceptance + J^T J).  The two
+ * schedules take the same steps; tests compare them.  Default 1. */
+void gorio_ugpm_debug_set_schedule(int speculative_rot);
+
 #ifdef __cplusplus
 }
 #endif

@@ -898,6 +898,8 @@ static SolveSummary ceres_like_solve(const LsqProblem& prob, VecX& x, int max_it
   };
   double cost = half_sq(r);
   sum.initial_cost = cost;
+  const bool lm_trace = std::getenv("UGPMO_LMTRACE") != nullptr;  // per-iteration solver trace on stderr (debugging aid)
+  if (lm_trace) std::fprintf(stderr, "[oracle lm] initial cost %.17g\n", cost);
   // Jacobi scaling fixed at the initial point
   VecX scale(n);
   for (int j = 0; j < n; j++) {
@@ -1006,6 +1008,7 @@ static SolveSummary ceres_like_solve(const LsqProblem& prob, VecX& x, int max_it
       break;
     }
     const double rho = cost_change / model_cost_change;
+    if (lm_trace) std::fprintf(stderr, "[oracle lm] iter %d cost %.17g cost_new %.17g radius %.6g mcc %.17g step_norm2 %.6g x_norm %.17g rho %.6g\n", iter, cost, cost_new, radius, model_cost_change, step_norm * step_norm, x_norm, rho);
     if (rho > min_relative_decrease) {
       x = x_new;
       x_norm = 0;
