@@ -31,4 +31,4 @@ def build(force: bool = False) -> str:
 from . import synth  # noqa: E402  (pure-numpy synthetic inputs, no GPU)
 from .apd import ApdGicp, ApdParams, DeviceInputs, GorioError, align_batch, load_library  # noqa: E402
 from . import prep  # noqa: E402
-from .ugpm import PreintOption, PreintPrior, UgpmBatch, VelPreintegration, ugpm_preint_batch, ugpm_stage_times  # noqa: E402
+from .ugpm import PreintOption, PreintPrior, UgpmBatch, VelPreintegration, ugpm_combine_preints, ugpm_preint_batch, ugpm_stage_times  # noqa: E402

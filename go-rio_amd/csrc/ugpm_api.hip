@@ -18,6 +18,7 @@
 #include "../../include/gorio_ugpm.h"
 #include "ugpm_kernels.hip"
 #include "ugpm_lpm_out.hip"
+#include "ugpm_chunks.h"
 
 using namespace gorio;
 
@@ -230,7 +231,8 @@ int gorio_ugpm_get_stage_times(double seconds[8], int counts[8]) {
   return 0;
 }
 
-int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gorio_ugpm_meas* out, gorio_ugpm_diag* diag, int device) {
+// every window non-chunked (quantum < 0): the device path
+static int preint_batch_flat(const gorio_ugpm_window* windows, int n_windows, gorio_ugpm_meas* out, gorio_ugpm_diag* diag, int device) {
   if (!windows || n_windows <= 0 || !out) return ufail(GORIO_UGPM_ERR_INVALID, "gorio_ugpm_preint_batch: bad arguments");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ufail(GORIO_UGPM_ERR_NO_DEVICE, "no usable HIP device (no CPU fallback exists)");
@@ -296,7 +298,7 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
     total_infer += std::max(0, w.n_infer);
     max_infer = std::max(max_infer, w.n_infer);
     if (!w.gyr_t || !w.gyr || !w.vel_t || !w.vel || !w.infer_t || w.n_infer <= 0) { win_fail(i, GORIO_UGPM_ERR_INVALID, "null pointers or no inference time"); continue; }
-    if (w.quantum >= 0) { win_fail(i, GORIO_UGPM_ERR_UNSUPPORTED, "chunked pre-integration (opt.quantum > 0, preint.h:1584-1702) is not supported; Go-RIO uses quantum = -1"); continue; }
+    if (w.quantum >= 0) { win_fail(i, GORIO_UGPM_ERR_INVALID, "a chunked request reached the device path"); continue; }  // gorio_ugpm_preint_batch expands them
     if (w.type != GORIO_UGPM_TYPE_UGPM && w.type != GORIO_UGPM_TYPE_LPM) { win_fail(i, GORIO_UGPM_ERR_INVALID, "unknown pre-integration type"); continue; }
     if (w.n_gyr < 2 || w.n_vel < 2) { win_fail(i, GORIO_UGPM_ERR_RANGE, "InterpolateLinear: this function need at least 2 data points to interpolate"); continue; }
     if (w.group_sizes && w.n_groups > 0) {
@@ -743,6 +745,120 @@ int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gor
   if (trace) std::fprintf(stderr, "[ugpm trace] prep %.3f ms, upload sync %.3f ms, kernels+polls %.3f ms, results %.3f ms\n", (tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (tt3 - tt2) * 1e3, (tnow() - tt3) * 1e3);
   if (first_error) return ufail(first_error, first_error_msg);
   return GORIO_UGPM_OK;
+}
+
+// Requests with opt.quantum >= 0 (preint.h:1584-1702) are cut into chunk windows (ugpm_chunks.h); the chunk windows of ALL such
+// requests join the other windows of the call in one device batch, and their records are chained on the host afterwards.
+int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gorio_ugpm_meas* out, gorio_ugpm_diag* diag, int device) {
+  if (!windows || n_windows <= 0 || !out) return ufail(GORIO_UGPM_ERR_INVALID, "gorio_ugpm_preint_batch: bad arguments");
+  bool any_chunked = false;
+  for (int i = 0; i < n_windows; ++i) any_chunked = any_chunked || windows[i].quantum >= 0;
+  if (!any_chunked) return preint_batch_flat(windows, n_windows, out, diag, device);
+  struct Req { int first = 0, count = 0, status = 0; chunks::Plan plan; size_t out0 = 0; };  // first/count: its windows in the expanded batch
+  std::vector<Req> reqs(n_windows);
+  std::vector<gorio_ugpm_window> flat;
+  std::vector<size_t> flat_out0;
+  int first_error = 0;
+  std::string first_error_msg;
+  size_t n_flat_out = 0, out_off = 0;
+  for (int i = 0; i < n_windows; ++i) {
+    const gorio_ugpm_window& w = windows[i];
+    Req& r = reqs[i];
+    r.out0 = out_off;
+    out_off += (size_t)std::max(0, w.n_infer);
+    r.first = (int)flat.size();
+    if (w.quantum < 0) {
+      r.count = 1;
+      flat.push_back(w);
+      flat_out0.push_back(n_flat_out);
+      n_flat_out += (size_t)std::max(0, w.n_infer);
+      continue;
+    }
+    std::string err;
+    if (!w.gyr_t || !w.gyr || !w.vel_t || !w.vel || !w.infer_t || w.n_infer <= 0) {
+      r.status = GORIO_UGPM_ERR_INVALID;
+      err = "null pointers or no inference time";
+    } else {
+      r.status = chunks::plan_chunks(w, r.plan, err);
+    }
+    if (r.status != 0) {
+      if (!first_error) {
+        first_error = r.status;
+        first_error_msg = "window " + std::to_string(i) + ": " + err;
+      }
+      continue;
+    }
+    for (chunks::Chunk& c : r.plan.chunks) {  // one ordinary window per chunk: VelPreintegration(data of the chunk, chunk start, stamps, quantum = -1), get(.., 0, 0)
+      gorio_ugpm_window cw = w;
+      cw.gyr_t = w.gyr_t + c.g0; cw.gyr = w.gyr + 3 * (size_t)c.g0; cw.n_gyr = c.ng;
+      cw.vel_t = w.vel_t + c.v0; cw.vel = w.vel + 3 * (size_t)c.v0; cw.n_vel = c.nv;
+      cw.start_t = c.start_t;
+      cw.infer_t = c.infer_t.data(); cw.n_infer = (int)c.infer_t.size();
+      cw.group_sizes = c.group_sizes.data(); cw.n_groups = (int)c.group_sizes.size();
+      cw.quantum = -1;
+      cw.vel_bias_std = 0.0; cw.gyr_bias_std = 0.0;
+      flat.push_back(cw);
+      flat_out0.push_back(n_flat_out);
+      n_flat_out += c.infer_t.size();
+    }
+    r.count = (int)r.plan.chunks.size();
+  }
+  const gorio_ugpm_meas nan_meas = [] {
+    gorio_ugpm_meas m;
+    double* p = reinterpret_cast<double*>(&m);
+    for (size_t k = 0; k < sizeof(m) / sizeof(double); ++k) p[k] = std::numeric_limits<double>::quiet_NaN();
+    return m;
+  }();
+  std::vector<gorio_ugpm_meas> flat_out(std::max<size_t>(1, n_flat_out), nan_meas);
+  std::vector<gorio_ugpm_diag> flat_diag(std::max<size_t>(1, flat.size()));
+  int rc = 0;
+  if (!flat.empty()) {
+    rc = preint_batch_flat(flat.data(), (int)flat.size(), flat_out.data(), flat_diag.data(), device);
+    bool per_window = false;  // a per-window failure leaves the other windows valid and is reported through the diagnostics; anything else fails the call
+    for (const gorio_ugpm_diag& d : flat_diag) per_window = per_window || d.status != 0;
+    if (rc != 0 && !per_window) return rc;
+  }
+  const std::string flat_msg = rc != 0 ? g_err : std::string();
+  for (int i = 0; i < n_windows; ++i) {
+    const gorio_ugpm_window& w = windows[i];
+    Req& r = reqs[i];
+    gorio_ugpm_meas* o = out + r.out0;
+    gorio_ugpm_diag d{};
+    if (r.status == 0 && w.quantum < 0) {
+      for (int k = 0; k < w.n_infer; ++k) o[k] = flat_out[flat_out0[r.first] + k];
+      d = flat_diag[r.first];
+      r.status = d.status;
+    } else if (r.status == 0) {
+      std::vector<const gorio_ugpm_meas*> recs;
+      for (int q = 0; q < r.count; ++q) {
+        const gorio_ugpm_diag& cd = flat_diag[r.first + q];
+        if (cd.status != 0 && r.status == 0) r.status = cd.status;
+        recs.push_back(flat_out.data() + flat_out0[r.first + q]);
+        // diagnostics of a chunked request: sizes and state frequency of its LAST chunk, iterations and costs summed over the chunks
+        d.nb_state = cd.nb_state; d.nb_gyr = cd.nb_gyr; d.nb_vel = cd.nb_vel; d.state_freq = cd.state_freq;
+        d.iters_rot += cd.iters_rot; d.iters_vel += cd.iters_vel; d.cost_rot += cd.cost_rot; d.cost_vel += cd.cost_vel;
+      }
+      if (r.status == 0) chunks::chain_chunks(r.plan, recs, w.vel_bias_std, w.gyr_bias_std, o);
+    }
+    if (r.status != 0) {
+      for (int k = 0; k < std::max(0, w.n_infer); ++k) o[k] = nan_meas;
+      if (!first_error) {
+        first_error = r.status;
+        first_error_msg = "window " + std::to_string(i) + (flat_msg.empty() ? std::string(": failed") : ": (expanded batch) " + flat_msg);
+      }
+    }
+    d.status = r.status;
+    if (diag) diag[i] = d;
+  }
+  if (first_error) return ufail(first_error, first_error_msg);
+  return 0;
+}
+
+/* combinePreints (math_utils.h:689-726) */
+int gorio_ugpm_combine_preints(const gorio_ugpm_meas* prev, const gorio_ugpm_meas* cur, gorio_ugpm_meas* out) {
+  if (!prev || !cur || !out) return ufail(GORIO_UGPM_ERR_INVALID, "gorio_ugpm_combine_preints: null pointer");
+  *out = chunks::combine_preints(*prev, *cur);
+  return 0;
 }
 
 }  // extern "C"

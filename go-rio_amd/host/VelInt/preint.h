@@ -3,7 +3,8 @@
 // Same class name, namespace, three constructors and three get() overloads, so radar_graph_slam_nodelet.cpp:497-513 compiles
 // unchanged.  The constructor ships the IMU window to the GPU through gorio_ugpm_preint_batch() (include/gorio_ugpm.h) with zero
 // bias standard deviations; get() adds the bias-prior inflation of PRE:1744-1757 on the host from the returned Jacobians (a 6x6
-// product), exactly as the reference applies it per call.  There is no CPU fallback: without a HIP device the constructor throws.
+// product), exactly as the reference applies it per call.  opt.quantum > 0 (chunked mode, PRE:1584-1702) is handled by the library:
+// every chunk is a window of the same device batch.  There is no CPU fallback: without a HIP device the constructor throws.
 #ifndef UGPM_2_H
 #define UGPM_2_H
 
@@ -113,7 +114,26 @@ public:
   }
   PreintPrior getPrior() { return prior_; }
 
-private:
+  // record <-> PreintMeas (public: combinePreints below uses them)
+  static gorio_ugpm_meas pack(const PreintMeas& o) {
+    gorio_ugpm_meas m;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        m.delta_R[r * 3 + c] = o.delta_R(r, c);
+        m.d_delta_R_d_bw[r * 3 + c] = o.d_delta_R_d_bw(r, c);
+        m.d_delta_p_d_bw[r * 3 + c] = o.d_delta_p_d_bw(r, c);
+        m.d_delta_p_d_bv[r * 3 + c] = o.d_delta_p_d_bv(r, c);
+      }
+      m.delta_p[r] = o.delta_p(r, 0);
+      m.d_delta_R_d_t[r] = o.d_delta_R_d_t(r, 0);
+      m.d_delta_p_d_t[r] = o.d_delta_p_d_t(r, 0);
+    }
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) m.cov[r * 6 + c] = o.cov(r, c);
+    m.dt = o.dt;
+    m.dt_sq_half = o.dt_sq_half;
+    return m;
+  }
   static PreintMeas unpack(const gorio_ugpm_meas& m) {
     PreintMeas o;
     for (int r = 0; r < 3; ++r) {
@@ -134,6 +154,7 @@ private:
     return o;
   }
 
+private:
   GyroVelData imu_data_;
   double start_t_;
   PreintOption opt_;
@@ -141,6 +162,15 @@ private:
   std::vector<std::vector<PreintMeas> > preint_;
   QueryType query_type_ = kVecVec;
 };
+
+// combinePreints (math_utils.h:689-726): the measurement of two consecutive intervals.  The chunked constructor (opt.quantum > 0,
+// PRE:1584-1702) chains its chunks with it inside the library; exported because the reference's header does.
+inline PreintMeas combinePreints(const PreintMeas& prev_preint, const PreintMeas& preint) {
+  const gorio_ugpm_meas a = VelPreintegration::pack(prev_preint), b = VelPreintegration::pack(preint);
+  gorio_ugpm_meas o;
+  if (gorio_ugpm_combine_preints(&a, &b, &o) != GORIO_UGPM_OK) throw std::runtime_error(std::string("combinePreints (gorio_amd): ") + gorio_ugpm_last_error());
+  return VelPreintegration::unpack(o);
+}
 
 }  // namespace ugpm
 #endif

@@ -1,7 +1,10 @@
 // Drives the drop-in ugpm::VelPreintegration the way Go-RIO's back end does (radar_graph_slam_nodelet.cpp:465-530):
 // fill GyroVelData from gyro / ego-velocity queues, PreintOption{type = UGPM}, one inference time, get(0, 0, 0.0, 0.0), read delta_R
 // and delta_p.  Input: binary [int n_g][n_g x (t, wx, wy, wz) double][int n_v][n_v x (t, vx, vy, vz) double][start_t][end_t].
+// An optional second argument is PreintOption::quantum (chunked mode, preint.h:1584-1702); the chained record is then also rebuilt
+// from two half-length constructions with ugpm::combinePreints (math_utils.h:689-726).
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include <VelInt/preint.h>
@@ -37,6 +40,7 @@ int main(int argc, char** argv) {
   ugpm::PreintPrior prior_bias;
   ugpm::PreintOption preint_opt;
   preint_opt.type = ugpm::UGPM;  // RGS:500
+  if (argc > 2) preint_opt.quantum = std::atof(argv[2]);
   std::vector<std::vector<double> > t(1, std::vector<double>(1, se[1]));  // RGS:505-508
   try {
     ugpm::VelPreintegration preintegration(imu_, se[0], t, preint_opt, prior_bias, true);  // RGS:512
@@ -51,6 +55,15 @@ int main(int argc, char** argv) {
       preintegration.get(3, 0);
       return 4;
     } catch (const std::range_error&) {  // PRE:1762
+    }
+    if (argc > 2) {  // combinePreints through the header: [start, mid] then [mid, end] as two plain constructions
+      ugpm::PreintOption plain = preint_opt;
+      plain.quantum = -1;
+      const double mid = 0.5 * (se[0] + se[1]);
+      ugpm::VelPreintegration first(imu_, se[0], mid, plain, prior_bias, true), second(imu_, mid, se[1], plain, prior_bias, true);
+      const ugpm::PreintMeas c = ugpm::combinePreints(first.get(0.0, 0.0), second.get(0.0, 0.0));
+      std::printf("{\"combined_dt\": %.17g, \"combined_delta_p\": [%.17g, %.17g, %.17g], \"combined_R00\": %.17g}\n", c.dt, c.delta_p(0, 0), c.delta_p(1, 0), c.delta_p(2, 0),
+                  c.delta_R(0, 0));
     }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "%s\n", e.what());

@@ -13,7 +13,8 @@ from .apd import GorioError, load_library
 LPM, UGPM = 0, 1
 REC = 83
 
-UGPM_SYMBOLS = ["gorio_ugpm_default_window", "gorio_ugpm_preint_batch", "gorio_ugpm_last_error", "gorio_ugpm_get_stage_times", "gorio_ugpm_debug_set_schedule"]
+UGPM_SYMBOLS = ["gorio_ugpm_default_window", "gorio_ugpm_preint_batch", "gorio_ugpm_last_error", "gorio_ugpm_get_stage_times", "gorio_ugpm_debug_set_schedule",
+                "gorio_ugpm_combine_preints"]
 
 
 class UgpmWindow(C.Structure):
@@ -77,7 +78,8 @@ class UgpmBatch:
             a.vel_t, a.vel, a.n_vel = _dp(vt), _dp(v), len(vt)
             a.gyr_var, a.vel_var, a.start_t = w["gyr_var"], w["vel_var"], w["start_t"]
             a.infer_t, a.n_infer = _dp(q), len(q)
-            a.type, a.min_freq, a.quantum, a.state_freq = int(type), min_freq, quantum, state_freq
+            a.type, a.min_freq, a.state_freq = int(type), min_freq, state_freq
+            a.quantum = float(quantum[i]) if np.ndim(quantum) > 0 else float(quantum)  # per-window list or one value; > 0 = chunked mode
             a.correlate, a.overlap = int(bool(correlate)), int(overlap)
             for k in range(3):
                 a.gyr_bias[k] = 0.0 if gyr_bias is None else float(gyr_bias[k])
@@ -123,6 +125,24 @@ def ugpm_preint_batch(windows, device=0, infer_t=None, type=UGPM, state_freq=50.
     if return_diag:
         return b.results(), b.diagnostics()
     return b.results()
+
+
+def pack(m):
+    """The gorio_ugpm_meas record (83 doubles) of an unpacked PreintMeas dict."""
+    return np.concatenate([np.asarray(m["delta_R"], np.float64).ravel(), np.asarray(m["delta_p"], np.float64), [m["dt"], m["dt_sq_half"]],
+                           np.asarray(m["cov"], np.float64).ravel(), np.asarray(m["d_delta_R_d_bw"], np.float64).ravel(), np.asarray(m["d_delta_R_d_t"], np.float64),
+                           np.asarray(m["d_delta_p_d_bw"], np.float64).ravel(), np.asarray(m["d_delta_p_d_bv"], np.float64).ravel(), np.asarray(m["d_delta_p_d_t"], np.float64)])
+
+
+def ugpm_combine_preints(prev, cur):
+    """gorio_ugpm_combine_preints = ugpm::combinePreints (VelInt/math_utils.h:689-726) on two PreintMeas dicts (host arithmetic)."""
+    lib = load_library()
+    a, b, out = np.ascontiguousarray(pack(prev)), np.ascontiguousarray(pack(cur)), np.zeros(REC)
+    lib.gorio_ugpm_combine_preints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib.gorio_ugpm_combine_preints(C.c_void_p(_dp(a)), C.c_void_p(_dp(b)), C.c_void_p(_dp(out)))
+    if rc < 0:
+        raise GorioError(rc, lib.gorio_ugpm_last_error().decode())
+    return unpack(out)
 
 
 def ugpm_debug_set_schedule(speculative_rot=True):

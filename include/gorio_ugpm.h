@@ -25,7 +25,7 @@ typedef enum {
   GORIO_UGPM_ERR_NO_DEVICE = -2,   /* no usable HIP device / HIP runtime error */
   GORIO_UGPM_ERR_RANGE = -3,       /* what the reference reports with std::range_error (MATH:493, PRE:680-686, TYPES:415) */
   GORIO_UGPM_ERR_ARGUMENT = -4,    /* std::invalid_argument of GyroVelData::get (TYPES:160) */
-  GORIO_UGPM_ERR_UNSUPPORTED = -5, /* chunked mode (opt.quantum > 0, PRE:1584-1702), more than 160 GP states */
+  GORIO_UGPM_ERR_UNSUPPORTED = -5, /* more than 160 GP states in one (chunk) window */
   GORIO_UGPM_ERR_NUMERIC = -6      /* a Cholesky factorisation met a non-positive pivot */
 } gorio_ugpm_status;
 
@@ -52,7 +52,11 @@ typedef struct {
   int n_infer;
   int type;           /* gorio_ugpm_type; default UGPM (TYPES:288).  LPM = IterativeIntegrator as the output method (PRE:1567-1580) over ALL samples given */
   double min_freq;    /* PreintOption::min_freq, default 500 (TYPES:287); the internal LPM passes always use 500 (PRE:1201) */
-  double quantum;     /* PreintOption::quantum, default -1 (no chunks); > 0 is unsupported */
+  double quantum;     /* PreintOption::quantum, default -1 (no chunks).  > 0: chunked mode (PRE:1584-1702): the request is cut into
+                         chunks of `quantum` seconds, every chunk is pre-integrated as a window of its own (all chunks of all requests
+                         in the same device batch) and the chunk results are chained with combinePreints (MATH:689-726).  0 is refused
+                         (the reference divides by it).  TYPES:36 declares Vec12 with nine rows, so the reference's covariance
+                         propagation (MATH:540-574) is undefined behaviour; the twelve components it addresses are used here */
   double state_freq;  /* PreintOption::state_freq, default 50 (TYPES:290) */
   int correlate;      /* PreintOption::correlate, default true (TYPES:291) */
   int overlap;        /* kOverlap = 8 (PRE:19) */
@@ -102,9 +106,13 @@ void gorio_ugpm_default_window(gorio_ugpm_window* w); /* PreintOption / PreintPr
  * n_windows constructions + get(0, j, vel_bias_std, gyr_bias_std) for every j < n_infer of every window.
  * out: sum of n_infer records, window-major in the order given.  diag: n_windows records or NULL.
  * A per-window failure (bad data) makes the call return that window's error code after all other windows were processed;
- * its records are filled with NaN.
+ * its records are filled with NaN.  diag of a chunked request: sizes and state frequency of its last chunk, iterations and costs
+ * summed over its chunks.
  */
 int gorio_ugpm_preint_batch(const gorio_ugpm_window* windows, int n_windows, gorio_ugpm_meas* out, gorio_ugpm_diag* diag, int device);
+
+/* combinePreints(prev, cur) (MATH:689-726): the pre-integrated measurement of two consecutive intervals; cur.dt == 0 returns prev. */
+int gorio_ugpm_combine_preints(const gorio_ugpm_meas* prev, const gorio_ugpm_meas* cur, gorio_ugpm_meas* out);
 
 const char* gorio_ugpm_last_error(void);
 

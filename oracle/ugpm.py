@@ -65,6 +65,58 @@ def preintegrate(win, infer_t=None, type=UGPM, min_freq=500.0, state_freq=50.0, 
     return [unpack(r) for r in out], d
 
 
+def pack(m):
+    """The 83-double record of an unpacked PreintMeas dict (inverse of unpack)."""
+    return np.concatenate([np.asarray(m["delta_R"], np.float64).ravel(), np.asarray(m["delta_p"], np.float64), [m["dt"], m["dt_sq_half"]],
+                           np.asarray(m["cov"], np.float64).ravel(), np.asarray(m["d_delta_R_d_bw"], np.float64).ravel(), np.asarray(m["d_delta_R_d_t"], np.float64),
+                           np.asarray(m["d_delta_p_d_bw"], np.float64).ravel(), np.asarray(m["d_delta_p_d_bv"], np.float64).ravel(), np.asarray(m["d_delta_p_d_t"], np.float64)])
+
+
+def preintegrate_chunked(win, quantum, infer_t=None, type=UGPM, min_freq=500.0, state_freq=50.0, correlate=True, overlap=8, gyr_bias=None, vel_bias=None,
+                         vel_bias_std=0.0, gyr_bias_std=0.0):
+    """ugpm::VelPreintegration with opt.quantum = `quantum` >= 0 (chunked mode, preint.h:1584-1702).
+
+    `infer_t`: None (one vector holding win["end_t"]), a flat sequence (one vector) or a list of sequences (the vector-of-vector constructor).
+    Returns (list per inner vector of unpacked PreintMeas dicts, diag dict).
+    """
+    gt, g = np.ascontiguousarray(win["gyr_t"], np.float64), np.ascontiguousarray(win["gyr"], np.float64)
+    vt, v = np.ascontiguousarray(win["vel_t"], np.float64), np.ascontiguousarray(win["vel"], np.float64)
+    if infer_t is None:
+        groups = [[win["end_t"]]]
+    elif len(infer_t) > 0 and np.ndim(infer_t[0]) > 0:
+        groups = [list(x) for x in infer_t]
+    else:
+        groups = [list(infer_t)]
+    q = np.ascontiguousarray([t for grp in groups for t in grp], np.float64)
+    sizes = (C.c_int * len(groups))(*[len(grp) for grp in groups])
+    out = np.zeros((max(1, len(q)), REC))
+    diag = np.zeros(8)
+    err = C.create_string_buffer(512)
+    gb = np.zeros(3) if gyr_bias is None else np.ascontiguousarray(gyr_bias, np.float64)
+    vb = np.zeros(3) if vel_bias is None else np.ascontiguousarray(vel_bias, np.float64)
+    rc = lib().ugpmo_preintegrate_chunked(
+        _p(gt), _p(g), len(gt), _p(vt), _p(v), len(vt), C.c_double(win["gyr_var"]), C.c_double(win["vel_var"]), C.c_double(win["start_t"]),
+        _p(q), sizes, len(groups), int(type), C.c_double(min_freq), C.c_double(state_freq), int(bool(correlate)), int(overlap), C.c_double(quantum),
+        _p(gb), _p(vb), C.c_double(vel_bias_std), C.c_double(gyr_bias_std), _p(out), _p(diag), err, 512)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    d = dict(nb_state=int(diag[0]), nb_gyr=int(diag[1]), nb_vel=int(diag[2]), iters_rot=int(diag[3]), iters_vel=int(diag[4]), cost_rot=diag[5],
+             cost_vel=diag[6], state_freq=diag[7])
+    res, o = [], 0
+    for grp in groups:
+        res.append([unpack(out[o + k]) for k in range(len(grp))])
+        o += len(grp)
+    return res, d
+
+
+def combine_preints(prev, cur):
+    """combinePreints(prev, cur) of math_utils.h:689-726 on two unpacked PreintMeas dicts."""
+    a, b = np.ascontiguousarray(pack(prev)), np.ascontiguousarray(pack(cur))
+    out = np.zeros(REC)
+    lib().ugpmo_combine_preints(_p(a), _p(b), _p(out))
+    return unpack(out)
+
+
 def states(win, state_freq=50.0, correlate=True, overlap=8, gyr_bias=None, vel_bias=None):
     """Optimised GP states [6, S] (mean-subtracted) and hyper-parameters [6, 4] = (l2, sf2, sz2, mean) of one UGPM window."""
     gt, g = np.ascontiguousarray(win["gyr_t"], np.float64), np.ascontiguousarray(win["gyr"], np.float64)

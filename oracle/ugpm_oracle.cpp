@@ -1719,6 +1719,252 @@ static void inflate_cov(PreintMeas& out, double vel_bias_std, double gyr_bias_st
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ chunked mode (PRE:1584-1702, MATH:206-314, 540-726)
+// The reference splits [start_t, last inference time] into chunks of opt.quantum seconds, pre-integrates every chunk on its own
+// (a non-chunked VelPreintegration over the samples of the chunk +- overlap periods) and chains the chunks with combinePreints.
+// ONE deliberate deviation, stated where it happens: TYPES:36 declares `Vec12` as a 9-vector, so the reference's covariance
+// propagation (MATH:540-574) reads and writes past the end of `eps` -- undefined behaviour, no defined result to follow.  The
+// restatement uses the 12 components the code plainly intends.  Everything else (delta_R, delta_p, dt, the five Jacobians) is
+// well defined in the reference and is followed operation by operation.
+static const double kLogTraceTolerance = 3.0 - kExpNormTolerance;  // MATH:12
+
+// jacobianLogMap, MATH:227-313: d log(R) / d vec(R) (3 x 9, vec column-major).  The reference spells every entry out (symbolic
+// toolbox output); they are three distinct expressions of c = R00/2 + R11/2 + R22/2 - 0.5, evaluated here in the reference's order.
+struct M39 {
+  double m[27];
+  double& operator()(int r, int c) { return m[r * 9 + c]; }
+  double operator()(int r, int c) const { return m[r * 9 + c]; }
+};
+static M39 jacobianLogMap(const M3& R) {
+  M39 o;
+  for (double& v : o.m) v = 0.0;
+  const double trace = R(0, 0) + R(1, 1) + R(2, 2);
+  if (trace < kLogTraceTolerance) {
+    const double c = R(0, 0) / 2.0 + R(1, 1) / 2.0 + R(2, 2) / 2.0 - 0.5;
+    const double half = std::acos(c) / (2 * std::pow(1 - std::pow(c, 2), 0.5));                  // the +-A entries
+    auto diag_term = [&](double u) {                                                             // u / (4 (c^2 - 1)) + acos(c) u c / (4 (1 - c^2)^1.5)
+      return u / (4 * (std::pow(c, 2) - 1)) + (std::acos(c) * u * c) / (4 * std::pow(1 - std::pow(c, 2), 1.5));
+    };
+    const double d0 = -diag_term(R(1, 2) - R(2, 1));  // MATH:236-258: - u/(..) - (..)
+    const double d1 = diag_term(R(0, 2) - R(2, 0));   // MATH:259-281
+    const double d2 = -diag_term(R(0, 1) - R(1, 0));  // MATH:282-304
+    o(0, 0) = d0; o(0, 4) = d0; o(0, 8) = d0; o(0, 5) = half; o(0, 7) = -half;
+    o(1, 0) = d1; o(1, 4) = d1; o(1, 8) = d1; o(1, 2) = -half; o(1, 6) = half;
+    o(2, 0) = d2; o(2, 4) = d2; o(2, 8) = d2; o(2, 1) = half; o(2, 3) = -half;
+  } else {  // MATH:306-309
+    o(0, 5) = 0.5; o(0, 7) = -0.5;
+    o(1, 2) = -0.5; o(1, 6) = 0.5;
+    o(2, 1) = 0.5; o(2, 3) = -0.5;
+  }
+  return o;
+}
+// jacobianYX(R) * jacobianExpMapZeroM(M)  (MATH:212-225, 342-349): 9 x 3, block b (rows 3b..3b+2) = R * E_b with
+// E_0 = [0; M row 2; -M row 1], E_1 = [-M row 2; 0; M row 0], E_2 = [M row 1; -M row 0; 0]
+struct M93 {
+  double m[27];
+  double& operator()(int r, int c) { return m[r * 3 + c]; }
+  double operator()(int r, int c) const { return m[r * 3 + c]; }
+};
+static M93 rot_times_exp_zero(const M3& R, const M3& M) {
+  double E[9][3];
+  for (int k = 0; k < 3; k++) {
+    E[0][k] = 0;        E[1][k] = M(2, k);  E[2][k] = -M(1, k);
+    E[3][k] = -M(2, k); E[4][k] = 0;        E[5][k] = M(0, k);
+    E[6][k] = M(1, k);  E[7][k] = -M(0, k); E[8][k] = 0;
+  }
+  M93 o;
+  for (int b = 0; b < 3; b++)
+    for (int i = 0; i < 3; i++)
+      for (int k = 0; k < 3; k++) {  // a 9 x 9 block-diagonal product in Eigen: the zero blocks contribute exact zeros, the order inside the block is j = 0, 1, 2
+        double acc = 0;
+        for (int j = 0; j < 3; j++) acc += R(i, j) * E[3 * b + j][k];
+        o(3 * b + i, k) = acc;
+      }
+  return o;
+}
+// propagateJacobianRp (matrix form MATH:577-593, vector form MATH:594-610: the vector form is the matrix form with one column)
+static void propagate_rp(const M3& R, const double* d_r, const V3& p, const double* d_p, int ncol, double* out /* 3 x ncol row-major */) {
+  M3 Mr = M3{{0}};
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < ncol; k++) Mr(i, k) = d_r[i * ncol + k];
+  const M93 dR = rot_times_exp_zero(R, Mr);
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < ncol; k++) {
+      double rd = 0;
+      for (int j = 0; j < 3; j++) rd += R(i, j) * d_p[j * ncol + k];
+      out[i * ncol + k] = ((rd + dR(i, k) * p[0]) + dR(3 + i, k) * p[1]) + dR(6 + i, k) * p[2];
+    }
+}
+// propagateJacobianRR (MATH:612-648 / 649-686): jacobianLogMap(R1 R2) * d vec(R1 R2)
+static void propagate_rr(const M3& R1, const double* d_r1, const M3& R2, const double* d_r2, int ncol, double* out /* 3 x ncol */) {
+  M3 M1 = M3{{0}}, M2 = M3{{0}};
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < ncol; k++) {
+      M1(i, k) = d_r1[i * ncol + k];
+      M2(i, k) = d_r2[i * ncol + k];
+    }
+  const M93 dR1 = rot_times_exp_zero(R1, M1), dR2 = rot_times_exp_zero(R2, M2);
+  double dRR[9][3];
+  for (int c = 0; c < 3; c++)      // column of R1 R2
+    for (int i = 0; i < 3; i++)    // row
+      for (int k = 0; k < ncol; k++) {
+        double rd = 0;
+        for (int j = 0; j < 3; j++) rd += R1(i, j) * dR2(3 * c + j, k);
+        dRR[3 * c + i][k] = ((rd + dR1(i, k) * R2(0, c)) + dR1(3 + i, k) * R2(1, c)) + dR1(6 + i, k) * R2(2, c);
+      }
+  const M39 JL = jacobianLogMap(mul(R1, R2));
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < ncol; k++) {
+      double acc = 0;
+      for (int q = 0; q < 9; q++) acc += JL(i, q) * dRR[q][k];
+      out[i * ncol + k] = acc;
+    }
+}
+// perturbationPropagation, MATH:540-553 (eps has the 12 components the code addresses; see the note above)
+static void perturbation_propagation(const double eps[12], const PreintMeas& prev, const PreintMeas& curr, double out[6]) {
+  const V3 e_r1 = {eps[0], eps[1], eps[2]}, e_p1 = {eps[3], eps[4], eps[5]}, e_r2 = {eps[6], eps[7], eps[8]}, e_p2 = {eps[9], eps[10], eps[11]};
+  const M3 exp_r1 = expMap(e_r1);
+  const M3 R_exp = mul(prev.delta_R, exp_r1);
+  const V3 r = logMap(mul(mul(mul(tr(curr.delta_R), exp_r1), curr.delta_R), expMap(e_r2)));
+  const V3 p = e_p1 + mul(R_exp, curr.delta_p + e_p2);
+  for (int i = 0; i < 3; i++) {
+    out[i] = r[i];
+    out[3 + i] = p[i];
+  }
+}
+// propagatePreintCov, MATH:556-574: forward differences with step 1e-5, then J blkdiag(prev.cov, curr.cov) J^T
+static void propagate_cov(const PreintMeas& prev, const PreintMeas& curr, double cov_out[36]) {
+  const double quantum = 1e-5;
+  double J[6][12], eps[12] = {0}, base[6], pert[6];
+  perturbation_propagation(eps, prev, curr, base);
+  for (int i = 0; i < 12; i++) {
+    eps[i] = quantum;
+    perturbation_propagation(eps, prev, curr, pert);
+    for (int a = 0; a < 6; a++) J[a][i] = (pert[a] - base[a]) / quantum;
+    eps[i] = 0;
+  }
+  double C[12][12] = {{0}};
+  for (int a = 0; a < 6; a++)
+    for (int b = 0; b < 6; b++) {
+      C[a][b] = prev.cov[a * 6 + b];
+      C[6 + a][6 + b] = curr.cov[a * 6 + b];
+    }
+  double T[6][12];
+  for (int a = 0; a < 6; a++)
+    for (int j = 0; j < 12; j++) {
+      double acc = 0;
+      for (int k = 0; k < 12; k++) acc += J[a][k] * C[k][j];
+      T[a][j] = acc;
+    }
+  for (int a = 0; a < 6; a++)
+    for (int b = 0; b < 6; b++) {
+      double acc = 0;
+      for (int k = 0; k < 12; k++) acc += T[a][k] * J[b][k];
+      cov_out[a * 6 + b] = acc;
+    }
+}
+// combinePreints, MATH:689-726
+static PreintMeas combinePreints(const PreintMeas& prev, const PreintMeas& preint) {
+  if (preint.dt == 0.0) return prev;
+  PreintMeas t = preint;
+  propagate_cov(prev, preint, t.cov);
+  M3 tmp;
+  // velocity-bias and gyro-bias Jacobians of the position (MATH:704-707)
+  t.d_delta_p_d_bv = add(prev.d_delta_p_d_bv, mul(prev.delta_R, t.d_delta_p_d_bv));
+  propagate_rp(prev.delta_R, prev.d_delta_R_d_bw.m, t.delta_p, t.d_delta_p_d_bw.m, 3, tmp.m);
+  t.d_delta_p_d_bw = add(prev.d_delta_p_d_bw, tmp);
+  propagate_rr(tr(t.delta_R), prev.d_delta_R_d_bw.m, t.delta_R, t.d_delta_R_d_bw.m, 3, tmp.m);  // MATH:708
+  t.d_delta_R_d_bw = tmp;
+  // time-shift Jacobians (MATH:711-713)
+  V3 v;
+  propagate_rp(prev.delta_R, prev.d_delta_R_d_t.data(), t.delta_p, t.d_delta_p_d_t.data(), 1, v.data());
+  t.d_delta_p_d_t = prev.d_delta_p_d_t + v;
+  propagate_rr(tr(t.delta_R), prev.d_delta_R_d_t.data(), t.delta_R, t.d_delta_R_d_t.data(), 1, v.data());
+  t.d_delta_R_d_t = v;
+  // chunk combination (MATH:717-722)
+  t.delta_p = prev.delta_p + mul(prev.delta_R, t.delta_p);
+  t.delta_R = mul(prev.delta_R, t.delta_R);
+  t.dt = prev.dt + t.dt;
+  t.dt_sq_half = 0.5 * t.dt * t.dt;
+  return t;
+}
+
+// A non-chunked VelPreintegration (PRE:1532-1581) reduced to what the chunk loop needs: its records by (group, index), un-inflated
+struct PlainPreint {
+  std::vector<std::vector<PreintMeas>> rec;
+  int nb_state = 0, nb_gyr = 0, nb_vel = 0, it_rot = 0, it_vel = 0;
+  double cost_rot = 0, cost_vel = 0, state_freq = 0;
+  PlainPreint(const GyroVelData& data, double start_t, const std::vector<std::vector<double>>& infer_t, int type, double min_freq, double state_freq_opt, bool correlate, int overlap,
+              const PreintPrior& prior) {
+    rec.resize(infer_t.size());
+    if (type == 1) {
+      std::vector<double> mx;
+      for (const auto& g : infer_t)
+        if (!g.empty()) mx.push_back(*std::max_element(g.begin(), g.end()));
+      if (mx.empty()) throw std::invalid_argument("chunk without inference times");
+      const double duration = *std::max_element(mx.begin(), mx.end()) - start_t;
+      Se3Integrator se3(data, start_t, prior, duration, state_freq_opt, overlap, correlate);
+      for (size_t i = 0; i < infer_t.size(); i++)
+        for (double t : infer_t[i]) rec[i].push_back(se3.get(t));
+      nb_state = se3.nb_state_; nb_gyr = se3.nb_gyr_; nb_vel = se3.nb_vel_;
+      it_rot = se3.sum_rot.iterations; it_vel = se3.sum_vel.iterations;
+      cost_rot = se3.sum_rot.final_cost; cost_vel = se3.sum_vel.final_cost;
+      state_freq = se3.state_freq_;
+    } else {
+      IterativeIntegrator lpm(data, start_t, prior, infer_t, min_freq, false, false);
+      for (size_t i = 0; i < infer_t.size(); i++)
+        for (size_t j = 0; j < infer_t[i].size(); j++) rec[i].push_back(lpm.get((int)i, (int)j));
+    }
+  }
+};
+
+// VelPreintegration with opt.quantum >= 0, PRE:1584-1702.  Returns the records by (group, index), un-inflated.
+static std::vector<std::vector<PreintMeas>> chunked_preint(const GyroVelData& imu, double start_t, const std::vector<std::vector<double>>& infer_t, int type, double min_freq,
+                                                          double state_freq, bool correlate, int overlap, double quantum, const PreintPrior& prior, double* diag) {
+  std::vector<double> temp_t;
+  for (const auto& t : infer_t)
+    if (!t.empty()) temp_t.push_back(t.back());
+  if (infer_t.empty() || infer_t[0].empty()) throw std::invalid_argument("chunked mode needs a non-empty first vector of inference times");
+  double last_t = infer_t[0].back();
+  if (temp_t.size() > 1) last_t = *std::max_element(temp_t.begin(), temp_t.end());
+  const double vel_period = (imu.vel.back().t - imu.vel[0].t) / (imu.vel.size() - 1);
+  const double gyr_period = (imu.gyr.back().t - imu.gyr[0].t) / (imu.gyr.size() - 1);
+  const double t_overlap = std::max(vel_period, gyr_period) * overlap;
+  int nb_chunks = (int)std::ceil((last_t - start_t) / quantum);
+  if (nb_chunks == 0) nb_chunks = 1;
+  std::vector<size_t> pointers(infer_t.size(), 0);
+  PreintMeas prev;
+  std::vector<std::vector<PreintMeas>> out(infer_t.size());
+  for (int i = 0; i < nb_chunks; i++) {
+    const double cs = start_t + (i * quantum);
+    double ce = start_t + ((i + 1) * quantum);
+    if (i == nb_chunks - 1) ce = std::numeric_limits<double>::infinity();
+    std::vector<std::vector<double>> sub(infer_t.size());
+    if (i != nb_chunks - 1) sub.push_back({ce});
+    for (size_t j = 0; j < infer_t.size(); j++)
+      while (pointers[j] < infer_t[j].size() && infer_t[j][pointers[j]] < ce) sub[j].push_back(infer_t[j][pointers[j]++]);
+    const GyroVelData data = imu.get(cs - t_overlap, ce + t_overlap);
+    PlainPreint pre(data, cs, sub, type, min_freq, state_freq, correlate, overlap, prior);
+    if (diag) {
+      diag[0] = pre.nb_state; diag[1] = pre.nb_gyr; diag[2] = pre.nb_vel;
+      diag[3] += pre.it_rot; diag[4] += pre.it_vel; diag[5] += pre.cost_rot; diag[6] += pre.cost_vel;
+      diag[7] = pre.state_freq;
+    }
+    const size_t n = infer_t.size();
+    if (i == 0) {
+      if (nb_chunks > 1) prev = pre.rec[n][0];
+      for (size_t j = 0; j < n; j++)
+        for (const PreintMeas& m : pre.rec[j]) out[j].push_back(m);
+    } else {
+      for (size_t j = 0; j < n; j++)
+        for (const PreintMeas& m : pre.rec[j]) out[j].push_back(combinePreints(prev, m));
+      if (i != nb_chunks - 1) prev = combinePreints(prev, pre.rec[n][0]);
+    }
+  }
+  return out;
+}
+
 }  // namespace ugpmo
 
 // ================================================================================================ C interface for ctypes
@@ -1803,6 +2049,66 @@ int ugpmo_preintegrate(const double* gyr_t, const double* gyr, int n_g, const do
     }
     return -1;
   }
+}
+
+/*
+ * ugpm::VelPreintegration with opt.quantum >= 0 (chunked mode, PRE:1584-1702) + get(i, j, vel_bias_std, gyr_bias_std) for every stamp.
+ * infer_t: the inner vectors laid end to end, group_sizes[n_groups] their lengths.  out: n_infer * 83 doubles, group-major.
+ * diag (may be null): as ugpmo_preintegrate, with [0..2], [7] of the LAST chunk and [3..6] summed over the chunks.
+ */
+int ugpmo_preintegrate_chunked(const double* gyr_t, const double* gyr, int n_g, const double* vel_t, const double* vel, int n_v, double gyr_var, double vel_var, double start_t,
+                               const double* infer_t, const int* group_sizes, int n_groups, int type, double min_freq, double state_freq, int correlate, int overlap, double quantum,
+                               const double* gyr_bias, const double* vel_bias, double vel_bias_std, double gyr_bias_std, double* out, double* diag, char* err, int err_cap) {
+  try {
+    using namespace ugpmo;
+    const GyroVelData data = make_data(gyr_t, gyr, n_g, vel_t, vel, n_v, gyr_var, vel_var);
+    PreintPrior prior;
+    for (int i = 0; i < 3; i++) {
+      prior.gyr_bias[i] = gyr_bias ? gyr_bias[i] : 0.0;
+      prior.vel_bias[i] = vel_bias ? vel_bias[i] : 0.0;
+    }
+    std::vector<std::vector<double>> groups(n_groups);
+    size_t o = 0;
+    for (int g = 0; g < n_groups; g++)
+      for (int k = 0; k < group_sizes[g]; k++) groups[g].push_back(infer_t[o++]);
+    if (diag)
+      for (int i = 0; i < 8; i++) diag[i] = 0;
+    const auto rec = chunked_preint(data, start_t, groups, type, min_freq, state_freq, correlate != 0, overlap, quantum, prior, diag);
+    o = 0;
+    for (int g = 0; g < n_groups; g++) {
+      if ((int)rec[g].size() != group_sizes[g]) throw std::range_error("VelPreintegration::get: Trying to get precomputed preintegrated measurements (wrong index query?)");
+      for (PreintMeas m : rec[g]) {
+        inflate_cov(m, vel_bias_std, gyr_bias_std);
+        pack(m, out + 83 * o++);
+      }
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && err_cap > 0) {
+      std::strncpy(err, e.what(), err_cap - 1);
+      err[err_cap - 1] = 0;
+    }
+    return -1;
+  }
+}
+
+/* combinePreints (MATH:689-726) on two packed records (83 doubles each, see pack()) */
+void ugpmo_combine_preints(const double* prev83, const double* cur83, double* out83) {
+  auto unpack = [](const double* o) {
+    ugpmo::PreintMeas m;
+    for (int i = 0; i < 9; i++) m.delta_R.m[i] = o[i];
+    for (int i = 0; i < 3; i++) m.delta_p[i] = o[9 + i];
+    m.dt = o[12];
+    m.dt_sq_half = o[13];
+    for (int i = 0; i < 36; i++) m.cov[i] = o[14 + i];
+    for (int i = 0; i < 9; i++) m.d_delta_R_d_bw.m[i] = o[50 + i];
+    for (int i = 0; i < 3; i++) m.d_delta_R_d_t[i] = o[59 + i];
+    for (int i = 0; i < 9; i++) m.d_delta_p_d_bw.m[i] = o[62 + i];
+    for (int i = 0; i < 9; i++) m.d_delta_p_d_bv.m[i] = o[71 + i];
+    for (int i = 0; i < 3; i++) m.d_delta_p_d_t[i] = o[80 + i];
+    return m;
+  };
+  pack(ugpmo::combinePreints(unpack(prev83), unpack(cur83)), out83);
 }
 
 /*

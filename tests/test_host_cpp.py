@@ -115,6 +115,28 @@ def test_backend_call_sequence_ugpm(gpu, gorio, tmp_path):
 
 
 @pytest.mark.gpu
+def test_backend_call_sequence_ugpm_chunked(gpu, gorio, tmp_path):
+    """The same driver with PreintOption::quantum = 0.4 (chunked mode, preint.h:1584-1702) and ugpm::combinePreints from the header."""
+    win = synth.imu_window(seed=12)
+    r = subprocess.run([PREINT_DRIVER, _imu_file(str(tmp_path), win), "0.4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    m = gorio.ugpm_preint_batch([win], quantum=0.4)[0][0]
+    assert np.allclose(np.array(lines[0]["delta_R"]).reshape(3, 3), m["delta_R"], rtol=0, atol=1e-15)
+    assert np.allclose(lines[0]["delta_p"], m["delta_p"], rtol=0, atol=1e-15)
+    assert lines[0]["dt"] == pytest.approx(1.0) and lines[0]["cov00"] == pytest.approx(m["cov"][0, 0], rel=1e-12)
+    mid = 0.5 * (win["start_t"] + win["end_t"])
+    first = gorio.ugpm_preint_batch([win], infer_t=[[mid]])[0][0]
+    w2 = dict(win)
+    w2["start_t"] = mid
+    second = gorio.ugpm_preint_batch([w2])[0][0]
+    c = gorio.ugpm_combine_preints(first, second)
+    assert lines[2]["combined_dt"] == pytest.approx(1.0)
+    assert np.allclose(lines[2]["combined_delta_p"], c["delta_p"], rtol=0, atol=1e-14) and lines[2]["combined_R00"] == pytest.approx(c["delta_R"][0, 0], abs=1e-15)
+    assert np.linalg.norm(c["delta_p"] - m["delta_p"]) < 2e-3  # two halves chained by hand ~ three chunks chained by the library
+
+
+@pytest.mark.gpu
 def test_host_class_edge_cases(gpu, gorio, tmp_path):
     """Empty clouds, covariance vectors of the wrong size and re-set clouds through the C++ class (APD:115-155)."""
     path, frames = _frames(str(tmp_path), n_frames=2)

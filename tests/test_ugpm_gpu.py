@@ -102,7 +102,7 @@ def test_class_surface_and_errors(gpu, gorio, ugpm_oracle):
     with pytest.raises(IndexError):
         pv.get(0, 5)  # preint.h:1760-1763
     with pytest.raises(gorio.GorioError):
-        gorio.ugpm_preint_batch([win], quantum=0.05)  # chunked mode: unsupported (and broken in the reference)
+        gorio.ugpm_preint_batch([win], quantum=0.0)  # the reference divides by opt.quantum (preint.h:1609)
     short = dict(win)
     short["gyr_t"], short["gyr"] = win["gyr_t"][:1], win["gyr"][:1]
     with pytest.raises(gorio.GorioError):
@@ -233,3 +233,88 @@ def test_rotation_fit_schedules_agree(gpu, gorio, ugpm_oracle):
         _, do = ugpm_oracle.preintegrate(w)
         assert d["iters_rot"] == do["iters_rot"] and d["iters_vel"] == do["iters_vel"]
         assert d["cost_rot"] == pytest.approx(do["cost_rot"], rel=0.05) or do["iters_rot"] == 50
+
+
+# ---------------------------------------------------------------------------------------------- chunked mode (f4, preint.h:1584-1702)
+def _cmp_chunked(a, b):
+    """Chained records: the gates of _cmp on the pose, looser bounds on what the chaining amplifies.  The position covariance of a
+    chained record is the previous chunk's ROTATION covariance times the lever arm squared (math_utils.h:540-574), i.e. 1e-3-relative
+    differences of chunk covariances show up at the same relative size but on entries six orders of magnitude apart."""
+    rot = np.linalg.norm(Rot.from_matrix(b["delta_R"].T @ a["delta_R"]).as_rotvec())
+    pos = np.linalg.norm(a["delta_p"] - b["delta_p"])
+    assert rot < 1e-4 and pos < 1e-4, (rot, pos)
+    assert a["dt"] == pytest.approx(b["dt"], abs=1e-12) and a["dt_sq_half"] == pytest.approx(b["dt_sq_half"], abs=1e-12)
+    sa, sb = np.sqrt(np.diag(a["cov"])), np.sqrt(np.diag(b["cov"]))
+    assert np.allclose(sa, sb, rtol=2e-3), (sa, sb)
+    assert np.allclose(a["cov"] / np.outer(sb, sb), b["cov"] / np.outer(sb, sb), atol=5e-3)
+    for k in ("d_delta_R_d_bw", "d_delta_R_d_t", "d_delta_p_d_bw", "d_delta_p_d_bv", "d_delta_p_d_t"):
+        assert np.allclose(a[k], b[k], rtol=1e-3, atol=1e-3 * max(np.abs(b[k]).max(), 1e-6)), k
+    return rot, pos
+
+
+def test_chunked_mode_matches_oracle(gpu, gorio, ugpm_oracle):
+    """opt.quantum > 0: a 2 s request in chunks of 0.7 s (three chunk windows in one device batch, chained on the host), stamps in
+    every chunk, with and without the bias-prior inflation, against the oracle's restatement of preint.h:1584-1702."""
+    win = synth.imu_window(seed=77, duration=2.0)
+    q = [win["start_t"] + 0.6, win["start_t"] + 1.3, win["start_t"] + 1.4, win["end_t"]]
+    for stds in ((0.0, 0.0), (0.3, 0.03)):
+        ro, do = ugpm_oracle.preintegrate_chunked(win, 0.7, infer_t=q, vel_bias_std=stds[0], gyr_bias_std=stds[1])
+        rg, dg = gorio.ugpm_preint_batch([win], infer_t=[q], quantum=0.7, vel_bias_std=stds[0], gyr_bias_std=stds[1], return_diag=True)
+        assert dg[0]["nb_state"] == do["nb_state"] and dg[0]["iters_rot"] == do["iters_rot"] and dg[0]["iters_vel"] == do["iters_vel"]
+        assert len(rg[0]) == 4
+        for a, b in zip(rg[0], ro[0]):
+            _cmp_chunked(a, b)
+    # the first stamp lies in the first chunk: its record is that of a plain window over the chunk's data, not chained
+    assert rg[0][0]["dt"] == pytest.approx(0.6)
+    # and the chained pose stays close to the one-piece pre-integration of the same request
+    rp = gorio.ugpm_preint_batch([win], infer_t=[q])
+    for a, b in zip(rg[0], rp[0]):
+        assert np.linalg.norm(Rot.from_matrix(b["delta_R"].T @ a["delta_R"]).as_rotvec()) < 2e-3 and np.linalg.norm(a["delta_p"] - b["delta_p"]) < 2e-3
+
+
+def test_chunked_mode_vector_of_vectors_lpm_type_and_mixed_batch(gpu, gorio, ugpm_oracle):
+    """Chunked requests beside plain ones in ONE call: a vector-of-vectors UGPM request, an LPM-type chunked request (chunks through
+    IterativeIntegrator, preint.h:1567-1580), a single chunk (quantum longer than the request) and two plain windows."""
+    w0 = synth.imu_window(seed=81, duration=1.6)
+    w1 = synth.imu_window(seed=82, duration=1.2)
+    w2 = synth.imu_window(seed=83, duration=1.0)
+    w3 = synth.imu_window(seed=84, duration=0.8)
+    g0 = [[w0["start_t"] + 0.3, w0["start_t"] + 0.9, w0["end_t"]], [w0["start_t"] + 0.55], [w0["start_t"] + 1.1, w0["start_t"] + 1.25]]
+    q0 = [t for g in g0 for t in g]
+    q1 = [w1["start_t"] + 0.5, w1["end_t"]]
+    q2 = [w2["end_t"]]
+    batch = gorio.UgpmBatch([w0, w3, w2, w1, w3], infer_t=[q0, [w3["end_t"]], q2, q1, [w3["end_t"]]], quantum=[0.5, -1.0, 5.0, 0.45, -1.0],
+                            groups=[[len(g) for g in g0], None, None, None, None])
+    batch.run()
+    res = batch.results()
+    ro0, _ = ugpm_oracle.preintegrate_chunked(w0, 0.5, infer_t=g0)
+    flat0 = [m for g in ro0 for m in g]
+    assert len(res[0]) == len(flat0) == 6
+    for a, b in zip(res[0], flat0):
+        _cmp_chunked(a, b)
+    ro2, _ = ugpm_oracle.preintegrate_chunked(w2, 5.0, infer_t=q2)  # one chunk: nothing is chained, but the chunk's data are those of [start - overlap periods, inf)
+    _cmp(res[2][0], ro2[0][0])
+    ro1, _ = ugpm_oracle.preintegrate_chunked(w1, 0.45, infer_t=q1)
+    for a, b in zip(res[3], ro1[0]):
+        _cmp_chunked(a, b)
+    plain, _ = ugpm_oracle.preintegrate(w3)
+    _cmp(res[1][0], plain[0])
+    assert np.array_equal(res[1][0]["delta_R"], res[4][0]["delta_R"]) and np.array_equal(res[1][0]["cov"], res[4][0]["cov"])
+    # LPM as the chunk integrator
+    rl, _ = ugpm_oracle.preintegrate_chunked(w1, 0.45, infer_t=q1, type=0)
+    gl = gorio.ugpm_preint_batch([w1], infer_t=[q1], quantum=0.45, type=0)
+    for a, b in zip(gl[0], rl[0]):
+        _cmp_chunked(a, b)
+
+
+def test_chunked_mode_through_the_class_and_errors(gpu, gorio, ugpm_oracle):
+    win = synth.imu_window(seed=85, duration=1.5)
+    data = dict(gyr_t=win["gyr_t"], gyr=win["gyr"], vel_t=win["vel_t"], vel=win["vel"], gyr_var=win["gyr_var"], vel_var=win["vel_var"])
+    opt = gorio.PreintOption(quantum=0.6)
+    p = gorio.VelPreintegration(data, win["start_t"], win["end_t"], opt)
+    ro, _ = ugpm_oracle.preintegrate_chunked(win, 0.6)
+    _cmp_chunked(p.get(vel_bias_std=0.0, gyr_bias_std=0.0), ro[0][0])
+    with pytest.raises(gorio.GorioError):
+        gorio.ugpm_preint_batch([win], infer_t=[[win["start_t"] - 1.0]], quantum=0.5)  # last stamp before start_t: no chunk
+    good = gorio.ugpm_preint_batch([win], quantum=0.6)
+    assert good[0][0]["dt"] == pytest.approx(1.5)
