@@ -47,7 +47,23 @@ def main():
                          **{k: np.asarray(v).tolist() for k, v in m.items()})
     json.dump(out, open(os.path.join(HERE, "ugpm_c2_windows.json"), "w"), indent=1)
     make_prep_golden(synth, apd, ugpm)
+    make_chunked_golden(synth, ugpm)
     print("golden fixtures written to", HERE)
+
+
+def chunked_inputs(synth):
+    """A 1.6 s request in chunks of 0.5 s (opt.quantum, preint.h:1584-1702): stamps in every chunk, one on a chunk boundary."""
+    win = synth.imu_window(seed=424250, duration=1.6)
+    s = win["start_t"]
+    return win, 0.5, [s + 0.2, s + 0.5, s + 0.95, s + 1.2, win["end_t"]]
+
+
+def make_chunked_golden(synth, ugpm):
+    win, quantum, q = chunked_inputs(synth)
+    res, d = ugpm.preintegrate_chunked(win, quantum, infer_t=q)
+    out = dict(quantum=quantum, diag={k: (float(v) if not isinstance(v, int) else v) for k, v in d.items()},
+               records=[{k: np.asarray(v).tolist() for k, v in m.items()} for m in res[0]])
+    json.dump(out, open(os.path.join(HERE, "ugpm_chunked.json"), "w"), indent=1)
 
 
 def prep_inputs(synth):
@@ -88,6 +104,17 @@ def make_prep_golden(synth, apd, ugpm):
                         lpm_delta_R=np.stack([m["delta_R"] for m in lpm]), lpm_delta_p=np.stack([m["delta_p"] for m in lpm]), lpm_cov=np.stack([m["cov"] for m in lpm]),
                         lpm_dt=np.array([m["dt"] for m in lpm]))
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "chunked":  # only the chunked-mode fixture (the others stay byte-identical)
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+    import importlib
+
+    import oracle
+    from oracle import ugpm as _u
+
+    oracle.build()
+    make_chunked_golden(importlib.import_module("go-rio_amd.synth"), _u)
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()

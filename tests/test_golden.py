@@ -66,6 +66,43 @@ def test_gpu_matches_ugpm_golden(gpu, gorio):
         assert np.allclose(m["cov"], g["cov"], rtol=1e-3, atol=1e-3 * np.abs(g["cov"]).max())
 
 
+# ---------------------------------------------------------------- chunked pre-integration (f4, preint.h:1584-1702)
+
+def _chunked_golden():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg.chunked_inputs(synth), json.load(open(os.path.join(GOLD, "ugpm_chunked.json")))
+
+
+def test_oracle_reproduces_chunked_golden():
+    import oracle
+    from oracle import ugpm
+
+    oracle.build()
+    (win, quantum, q), gold = _chunked_golden()
+    res, d = ugpm.preintegrate_chunked(win, quantum, infer_t=q)
+    assert d["iters_rot"] == gold["diag"]["iters_rot"] and d["iters_vel"] == gold["diag"]["iters_vel"]
+    for m, g in zip(res[0], gold["records"]):
+        for k in g:
+            assert np.allclose(m[k], g[k], rtol=1e-9, atol=1e-12), k
+
+
+@pytest.mark.gpu
+def test_gpu_matches_chunked_golden(gpu, gorio):
+    (win, quantum, q), gold = _chunked_golden()
+    res, d = gorio.ugpm_preint_batch([win], infer_t=[q], quantum=quantum, return_diag=True)
+    assert d[0]["iters_rot"] == gold["diag"]["iters_rot"] and d[0]["iters_vel"] == gold["diag"]["iters_vel"]
+    assert len(res[0]) == len(gold["records"]) == 5
+    for m, g in zip(res[0], gold["records"]):
+        rot = np.linalg.norm(Rot.from_matrix(np.array(g["delta_R"]).T @ m["delta_R"]).as_rotvec())
+        assert rot < 1e-4 and np.linalg.norm(m["delta_p"] - np.array(g["delta_p"])) < 1e-4 and m["dt"] == pytest.approx(g["dt"], abs=1e-12)
+        sg = np.sqrt(np.diag(np.array(g["cov"])))
+        assert np.allclose(np.sqrt(np.diag(m["cov"])), sg, rtol=2e-3)
+
+
 # ---------------------------------------------------------------- preprocessing (f3), submap assembly (f4), LPM output type (a8)
 
 def _prep_golden():
