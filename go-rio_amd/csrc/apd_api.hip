@@ -596,6 +596,20 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     j.regularization = h->params.regularization;
     j.splits = s;
     j.chunk_len = chunk;
+    j.qpw = 64;
+    j.pad0_ = 0;
+  }
+  // queries per wave of the selection kernels: halved while the call has fewer waves than the chip has SIMDs (1024)
+  int qpw = 64;
+  {
+    long w64 = 0;
+    for (int q = 0; q < njobs; ++q) w64 += (jobs[q].cloud.idx.n + 63) / 64;
+    while (qpw > 8 && w64 * (64 / qpw) < 1024) qpw /= 2;
+    if (const char* e = std::getenv("GORIO_KNN_QPW")) {  // experiments (profiles/r03/experiments.md)
+      const int v = std::atoi(e);
+      if (v == 8 || v == 16 || v == 32 || v == 64) qpw = v;
+    }
+    for (int q = 0; q < njobs; ++q) jobs[q].qpw = qpw;
   }
   if (njobs > lead->jobs_cap) {
     hipFree(lead->d_jobs);
@@ -610,7 +624,7 @@ int run_covariances(gorio_apd* lead, std::vector<std::pair<gorio_apd*, DevCloud*
     dim3 gp((roundup(max_n, 512) + 255) / 256, 1, njobs);
     if (K == 20) {
       if (pruned) {
-        const dim3 gs(gp.x * (256 / kKnnBlock), 1, njobs);
+        const dim3 gs(gp.x * (256 / qpw), 1, njobs);
         knn_kth_kernel<20><<<gs, kKnnBlock, 0, lead->stream>>>(lead->d_jobs);
         knn_collect_kernel<20><<<gs, kKnnBlock, 0, lead->stream>>>(lead->d_jobs);
         knn_pruned_kernel<20><<<gp, 256, 0, lead->stream>>>(lead->d_jobs);  // only the waves knn_collect_kernel flagged (massive ties) do anything

@@ -116,6 +116,8 @@ struct KnnJob {
   int regularization;
   int splits;
   int chunk_len;  // multiple of 16
+  int qpw;        // queries per wave of knn_kth_kernel / knn_collect_kernel: 64 when the call fills the chip, 32 / 16 / 8 when it does not
+  int pad0_;
 };
 
 struct ApdConsts {

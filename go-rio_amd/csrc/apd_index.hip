@@ -1143,7 +1143,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 //                       (covariance_from_list) as before.
 // A wave in which some lane meets more than CAP candidates at or below its d_k (only with many exactly equal distances: lattices,
 // duplicated points) flags itself in job.redo and is redone by knn_pruned_kernel, so the result is exact for every input.
-// grid of both: (ceil(n_spad / kKnnBlock), 1, clouds), block kKnnBlock (one wave: the waves never cooperate, see nn_search_pruned_kernel).
+// grid of both: (ceil(n_spad / qpw), 1, clouds), block kKnnBlock (one wave: the waves never cooperate, see nn_search_pruned_kernel).
+// qpw = KnnJob::qpw queries per wave (64, 32, 16 or 8; the other lanes idle).  A wave walks the UNION of the tiles its queries need, and
+// its life grows with that union; when the call has fewer 64-query waves than the chip has SIMDs (a lone pair of scans) smaller groups
+// give more, shorter waves: a lone 5 k x 5 k align 0.79 -> 0.73 ms.  (It does not shorten the slow waves of a big map -- 44 of the 1564
+// waves of a 100 k-point map take 2.5 x the average with 3 x the tiles and insertions, whatever the group size: profiles/r03/experiments.md.)
 #ifndef GORIO_KNN_BLOCK
 #define GORIO_KNN_BLOCK 64
 #endif
@@ -1154,9 +1158,12 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __rest
   const KnnJob& job = jobs[blockIdx.z];
   const SearchIndex& si = job.cloud.idx;
   const int n = si.n;
-  const int p = blockIdx.x * kKnnBlock + threadIdx.x;
-  if (blockIdx.x * kKnnBlock >= n) return;
+  const int qpw = job.qpw;  // queries per wave (see KnnJob): lanes qpw .. 63 idle
+  const int base = blockIdx.x * qpw;
+  if (base >= n) return;
   const int lane = threadIdx.x & 63;
+  const bool live = lane < qpw;
+  const int p = base + (live ? lane : 0);
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
   const float qlo[3] = {wave_fmin_u(qx), wave_fmin_u(qy), wave_fmin_u(qz)};  // DPP reductions, wave-uniform results
@@ -1166,11 +1173,12 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __rest
   const scalar_fp tz = as_scalar(si.sz);
   const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
   const int ng = (si.n_tiles + 63) / 64;
-  const int own_tile = __builtin_amdgcn_readfirstlane((blockIdx.x * kKnnBlock + (threadIdx.x & ~63)) / 32);
+  const int own_tile = __builtin_amdgcn_readfirstlane(base / 32);
   const int g0 = own_tile / 64;
-  float D[K];  // the K smallest distances met so far, ascending
+  if (lane == 0) job.redo[base >> 6] = 0;  // knn_collect_kernel raises it; with qpw < 64 several waves share one flag
+  float D[K];  // the K smallest distances met so far, ascending.  An idle lane holds -inf throughout: it needs no tile, accepts no candidate
 #pragma unroll
-  for (int t = 0; t < K; ++t) D[t] = INFINITY;
+  for (int t = 0; t < K; ++t) D[t] = live ? INFINITY : -INFINITY;
   for (int v = 0; v < 2 * ng; ++v) {
     const int off = (v + 1) >> 1;
     const int g = (v & 1) ? g0 - off : g0 + off;
@@ -1214,7 +1222,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __rest
       }
     }
   }
-  job.kth[p] = D[K - 1];  // indexed by SORTED position (n_spad entries)
+  if (live) job.kth[p] = D[K - 1];  // indexed by SORTED position (n_spad entries)
 }
 
 template <int K>
@@ -1222,9 +1230,12 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
   const KnnJob& job = jobs[blockIdx.z];
   const SearchIndex& si = job.cloud.idx;
   const int n = si.n;
-  const int p = blockIdx.x * kKnnBlock + threadIdx.x;
-  if (blockIdx.x * kKnnBlock >= n) return;
+  const int qpw = job.qpw;
+  const int base = blockIdx.x * qpw;
+  if (base >= n) return;
   const int lane = threadIdx.x & 63;
+  const bool live = lane < qpw;
+  const int p = base + (live ? lane : 0);
   const int pq = p < n ? p : n - 1;
   const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
   const float qlo[3] = {wave_fmin_u(qx), wave_fmin_u(qy), wave_fmin_u(qz)};  // DPP reductions, wave-uniform results
@@ -1237,7 +1248,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
   constexpr int CAP = K + 4;
   __shared__ unsigned long long s_buf[CAP][kKnnBlock];  // keys at or below d_k, one column per lane (bank = lane: conflict free)
   const int ng = (si.n_tiles + 63) / 64;
-  const float dk = job.kth[p];
+  const float dk = live ? job.kth[p] : -INFINITY;  // an idle lane needs no tile and keeps no candidate
   STAT_ADD(0, 1);
   int cnt = 0;
   {
@@ -1276,8 +1287,10 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
     }
   }
   const bool redo = __ballot(cnt > CAP) != 0ull;
-  if (lane == 0) job.redo[(blockIdx.x * kKnnBlock + threadIdx.x) >> 6] = redo ? 1 : 0;
-  if (redo) return;
+  if (redo) {
+    if (lane == 0) job.redo[base >> 6] = 1;  // cleared by knn_kth_kernel; knn_pruned_kernel redoes the 64 sorted positions of the flag
+    return;
+  }
   // sort the buffered keys (ties fall to the lower original index, surplus ties beyond K drop off the end)
   unsigned long long L[K];
 #pragma unroll
@@ -1288,7 +1301,7 @@ __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __
   for (int r = 0; r < rounds; ++r) {
     if (r < cnt) topk_insert_key<K>(L, s_buf[r][threadIdx.x]);
   }
-  if (p < n) {
+  if (live && p < n) {
     float bd[K];
     int bi[K];
 #pragma unroll
