@@ -565,7 +565,7 @@ static int preint_batch_flat(const gorio_ugpm_window* windows, int n_windows, go
       const int tpg = which == 2 ? kAtaTilesCorr : kAtaTilesLm;
       const int ng = (ntile + tpg - 1) / tpg;
       const int npad = ((n + 15) / 32) * 32 + 16;
-      const int units = r.nw * ng, grid = ((units + 7) / 8) * 8;
+      const int grid = ((r.nw + 7) / 8) * ng * 8;  // 8 windows (one per XCD) x ng tile groups per slice of the grid
       const UgpmWin* dw_ = c.d_wins + r.g0;
       // LDS as small as the staging needs (53 KB at n = 198): the scan matcher's kernels share the CUs with these workgroups
       auto lds = [&](int kc) { return sizeof(double) * 2 * kc * (npad + 1); };

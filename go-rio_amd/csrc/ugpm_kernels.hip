@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict
 // workgroup owns a group over ALL rows of A.  It streams the rows through LDS in chunks of 16 (8 for n > 496) -- every element of
 // A is read from L2 once per group instead of once per output tile -- and writes C symmetrically.  (Splitting the rows over several
 // workgroups with partial tiles, an arrival counter and an ordered reduction was measured in round 1 and dropped.)
-// grid: 1-D, ceil(units / 8) * 8 workgroups with unit = (window, group).
+// grid: 1-D, ceil(windows / 8) * groups * 8 workgroups (window and group from the workgroup number, see the kernel).
 // which: 0 rot problem, 1 vel problem, 2 correlation.  Dynamic LDS: 2 * KC * (npad + 1) doubles.  n <= 512 when g is formed.
 // decide (LM problems): take the step acceptance test first, see below.
 __device__ __forceinline__ int ata_npad(int n) { return ((n + 15) / 32) * 32 + 16; }  // >= round_up(n, 16); rows 32 banks apart
@@ -1789,10 +1789,16 @@ __device__ __forceinline__ int ata_npad(int n) { return ((n + 15) / 32) * 32 + 1
 // TPG / 8 accumulators): 32 for the LM problems (n = 3S: more, shorter workgroups), 48 for the correlation (n = 6S).
 template <int CMAX, int KC, int TPG>
 __global__ __launch_bounds__(512) void ata_kernel(const UgpmWin* __restrict__ wins, int which, int n_windows, int groups_max, int decide) {
+  // Consecutive workgroups of a launch go round-robin to the 8 XCDs, each with an L2 of its own: ALL tile groups of a window are given
+  // workgroup numbers of one residue mod 8, 8 apart, so they start together on ONE XCD and stream the window's J through that L2 side
+  // by side (one fetch from HBM / MALL serves the groups) instead of once per XCD.
   const int L = blockIdx.x;
-  const int xcd = L & 7, pslot = L >> 3;
-  const int unit = pslot * 8 + xcd;
-  const int win = unit / groups_max, grp = unit % groups_max;
+  const int xcd = L & 7, slot = L >> 3;
+#ifdef GORIO_ATA_NO_XCD
+  const int win = (slot * 8 + xcd) / groups_max, grp = (slot * 8 + xcd) % groups_max;
+#else
+  const int win = (slot / groups_max) * 8 + xcd, grp = slot % groups_max;
+#endif
   if (win >= n_windows) return;
   const UgpmWin w = load_win(wins, win);
   if (*w.status != 0) return;
