@@ -104,6 +104,34 @@ struct PairDesc {
   int pad_;
 };
 
+// XCD-aware placement of a (x, y, units) launch whose third grid dimension counts independent units (scan pairs, clouds): the hardware
+// deals consecutive workgroups round-robin to the 8 XCDs, each with an L2 of its own, so with the plain (blockIdx.x, blockIdx.z) numbering
+// every XCD sees every unit's clouds.  Here unit u runs entirely on XCD u mod 8 -- its source, target, boxes and covariances stay in ONE
+// L2 -- by renumbering: workgroup L (linear launch order) -> xcd = L mod 8, slot = L / 8, unit = (slot / inner) * 8 + xcd, inner index
+// = slot mod inner.  Only when there are at least 16 units in multiples of 8 (a lone pair must keep the whole chip).
+#ifndef GORIO_XCD_UNITS
+#define GORIO_XCD_UNITS 1
+#endif
+struct GridPos {
+  unsigned int x, y, z;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ GridPos xcd_grid_pos() {
+  GridPos g{blockIdx.x, blockIdx.y, blockIdx.z};
+#if GORIO_XCD_UNITS
+  if (gridDim.z >= 16u && (gridDim.z & 7u) == 0u) {
+    const unsigned int inner = gridDim.x * gridDim.y;
+    const unsigned int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned int slot = L >> 3, in = slot % inner;
+    g.z = (slot / inner) * 8u + (L & 7u);
+    g.x = in % gridDim.x;
+    g.y = in / gridDim.x;
+  }
+#endif
+  return g;
+}
+#endif
+
 struct KnnJob {
   CloudView cloud;
   float* part_d;  // [splits][K][n]

@@ -573,6 +573,9 @@ __device__ __forceinline__ void lds_read8_b128(v4f_t (&c)[8], unsigned int addr)
 }
 
 __global__ __launch_bounds__(kNnBlock) __attribute__((amdgpu_waves_per_eu(GORIO_NN_WAVES, GORIO_NN_WAVES))) void nn_search_pruned_kernel(const PairDesc* __restrict__ descs, float bound_f, int mode) {
+  // (No pair -> XCD renumbering here, unlike linearize_kernel and the k-NN kernels: measured, it changes nothing for 64 pairs with targets
+  // of their own -- 1.89 ms per 20 launches either way -- and costs 12 % against a shared 1 M-point map, where it only takes away the
+  // balance of the heaviest-first work list.)
   const PairDesc& pd = descs[blockIdx.z];
   // the optimiser state is constant while this kernel runs: read it through the scalar cache (a generic pointer would make these flat
   // loads, whose completion the compiler can only wait for together with every other outstanding load)
@@ -1155,11 +1158,12 @@ constexpr int kKnnBlock = GORIO_KNN_BLOCK;
 
 template <int K>
 __global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __restrict__ jobs) {
-  const KnnJob& job = jobs[blockIdx.z];
+  const GridPos gp = xcd_grid_pos();  // cloud -> XCD (apd_device.h)
+  const KnnJob& job = jobs[gp.z];
   const SearchIndex& si = job.cloud.idx;
   const int n = si.n;
   const int qpw = job.qpw;  // queries per wave (see KnnJob): lanes qpw .. 63 idle
-  const int base = blockIdx.x * qpw;
+  const int base = gp.x * qpw;
   if (base >= n) return;
   const int lane = threadIdx.x & 63;
   const bool live = lane < qpw;
@@ -1227,11 +1231,12 @@ __global__ __launch_bounds__(kKnnBlock) void knn_kth_kernel(const KnnJob* __rest
 
 template <int K>
 __global__ __launch_bounds__(kKnnBlock) void knn_collect_kernel(const KnnJob* __restrict__ jobs) {
-  const KnnJob& job = jobs[blockIdx.z];
+  const GridPos gp = xcd_grid_pos();  // cloud -> XCD (apd_device.h)
+  const KnnJob& job = jobs[gp.z];
   const SearchIndex& si = job.cloud.idx;
   const int n = si.n;
   const int qpw = job.qpw;
-  const int base = blockIdx.x * qpw;
+  const int base = gp.x * qpw;
   if (base >= n) return;
   const int lane = threadIdx.x & 63;
   const bool live = lane < qpw;

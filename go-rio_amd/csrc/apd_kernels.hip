@@ -491,7 +491,8 @@ __device__ __forceinline__ float sumsq2_f(float a, float b) {  // x^2 + y^2 in f
 // fuse != 0 (Gauss-Newton aligns): the workgroup that stores the LAST partial of its pair goes on to run the optimiser step
 // (gn_step_tail) -- the partials are summed in block order whoever sums them, so the result is the one lm_solve_kernel gives, one launch earlier.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void linearize_kernel(const PairDesc* __restrict__ descs, ApdConsts cst, int fuse) {
-  const PairDesc& pd = descs[blockIdx.z];
+  const GridPos gp = xcd_grid_pos();  // pair -> XCD (apd_device.h)
+  const PairDesc& pd = descs[gp.z];
   PairState* __restrict__ st = pd.state;
   // the optimiser state is constant until the LAST workgroup of the launch rewrites it (gn_step_tail, after every other workgroup has
   // arrived): read it through the scalar cache.  Through the generic pointer these would be flat loads, whose completion the compiler
@@ -499,8 +500,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   const __attribute__((address_space(4))) PairState* sst = (const __attribute__((address_space(4))) PairState*)pd.state;
   if (sst->done) return;
   const int n = pd.src.n;
-  if (blockIdx.x * 256 >= n) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (gp.x * 256 >= (unsigned int)n) return;
+  const int i = gp.x * 256 + threadIdx.x;
 
   double acc[28];
 #pragma unroll
@@ -656,13 +657,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   if (threadIdx.x < 28) {
     const double s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     if (!fuse) {
-      pd.partials[(size_t)blockIdx.x * 28 + threadIdx.x] = s;
+      pd.partials[(size_t)gp.x * 28 + threadIdx.x] = s;
     } else {
       // Hand-over to the last workgroup of the pair WITHOUT a device-scope fence: on this part a release fence writes back the
       // whole L2 of the XCD (the eight XCDs have private L2s), and 4096 workgroups doing that cost 0.6 ms per launch.  The partial
       // is stored write-through (agent-scope store, `sc1`), the wave waits for the store to be acknowledged, and only then is the
       // arrival counted; the consumer reads the partials with agent-scope loads.
-      __hip_atomic_store(pd.partials + (size_t)blockIdx.x * 28 + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(pd.partials + (size_t)gp.x * 28 + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (!fuse) return;
