@@ -37,6 +37,32 @@ __device__ __forceinline__ UgpmWin load_win(const UgpmWin* __restrict__ wins, in
 }
 
 
+// XCD-aware placement of a (parts, windows, z) launch: consecutive workgroups go round-robin to the 8 XCDs, so with the plain numbering
+// the workgroups of one window -- which share its matrices -- land on different L2s.  Renumbered, window w runs entirely on XCD w mod 8
+// (workgroup L in launch order -> xcd = L mod 8, slot = L / 8, window = (slot / inner) * 8 + xcd, inner index = slot mod inner), the
+// XCD the (windows, parts) launches of the LM kernels put it on anyway when the window count is a multiple of 8.  Only with at least 16
+// windows in multiples of 8; otherwise the plain numbering.
+#ifndef GORIO_UGPM_XCD
+#define GORIO_UGPM_XCD 1
+#endif
+struct WinPart {
+  int win, part, z;
+};
+__device__ __forceinline__ WinPart xcd_win_part() {
+  WinPart r{(int)blockIdx.y, (int)blockIdx.x, (int)blockIdx.z};
+#if GORIO_UGPM_XCD
+  if (gridDim.y >= 16u && (gridDim.y & 7u) == 0u) {
+    const unsigned int inner = gridDim.x * gridDim.z;
+    const unsigned int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned int slot = L >> 3, in = slot % inner;
+    r.win = (int)((slot / inner) * 8u + (L & 7u));
+    r.part = (int)(in % gridDim.x);
+    r.z = (int)(in / gridDim.x);
+  }
+#endif
+  return r;
+}
+
 constexpr double kDt = 0.01;        // kNumDtJacobianDelta, math_utils.h:15
 constexpr double kBw = 0.0001;      // kNumGyrBiasJacobianDelta, math_utils.h:17
 constexpr double kExpTol = 1e-14;   // kExpNormTolerance, math_utils.h:11
@@ -1189,9 +1215,10 @@ __device__ __forceinline__ void small_gemm_nn(const double* __restrict__ A, cons
 // grid: (6 channels, windows), block 256.  preint.h:832-866 for one channel: K + sz2 I = L L^T (block_cholesky), L^-1 by the
 // blocked 16-column forward substitution, K^-1 = L^-T L^-1, K K^-1 and K_int K^-1 on the matrix cores.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin w = load_win(wins, blockIdx.y);
+  const WinPart wp = xcd_win_part();
+  const UgpmWin w = load_win(wins, wp.win);
   if (*w.status != 0) return;
-  const int c = blockIdx.x, S = w.S;
+  const int c = wp.part, S = w.S;
   const double l2 = w.hyper[c * 4 + 0], sf2 = w.hyper[c * 4 + 1], sz2 = w.hyper[c * 4 + 2];
   double* A = w.Kinv + (size_t)c * S * S;    // K + sz2 I -> L -> finally K^-1
   double* B = w.KKinv + (size_t)c * S * S;   // L^-1 scratch -> finally K K^-1
@@ -1261,9 +1288,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // 6-8 K_s_int K^-1 (velocity stamps, rotation channels), 9-11 K_s K^-1 (velocity stamps, velocity channels).
 constexpr int kCrossRows = 32;  // table rows per workgroup (8 made 25 k tiny workgroups per batch: dispatch bound)
 __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin w = load_win(wins, blockIdx.y);
+  const WinPart wp = xcd_win_part();
+  const UgpmWin w = load_win(wins, wp.win);
   if (*w.status != 0) return;
-  const int tab = blockIdx.x, S = w.S;
+  const int tab = wp.part, S = w.S;
   const int c = tab % 3, kind = tab / 3;
   const int ch = kind == 3 ? 3 + c : c;
   const int N = kind < 2 ? w.G : w.V;
@@ -1277,7 +1305,7 @@ __global__ __launch_bounds__(256) void cross_kernel(const UgpmWin* __restrict__ 
   const int LDK = ((S + 31) / 32) * 32 + 4;
   extern __shared__ double ks_dyn[];
   double* ks = ks_dyn;  // [kCrossRows][LDK]
-  const int row0 = blockIdx.z * kCrossRows;
+  const int row0 = wp.z * kCrossRows;
   if (row0 >= N) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int r = wave; r < kCrossRows; r += 4) {  // kernel rows k(t_n, state_t[.]) of this tile; rows past N and columns past S are zero
@@ -1668,10 +1696,11 @@ __global__ __launch_bounds__(256) void vel_eval_kernel(const UgpmWin* __restrict
 // 512-byte stores, no index arithmetic beyond adds).
 constexpr int kCorrJacParts = 16;
 __global__ __launch_bounds__(256) void corr_jac_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin w = load_win(wins, blockIdx.y);
+  const WinPart wp = xcd_win_part();
+  const UgpmWin w = load_win(wins, wp.win);
   if (*w.status != 0 || !w.correlate) return;
   const int S = w.S, G = w.G, V = w.V, n = 6 * S;
-  const int part = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int part = wp.part, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* J = w.Jc;
   const double wgt = sqrt(1.0 / w.vel_var);
   // ---- gyro samples i = part, part + kCorrJacParts, ...: table dot products by whole waves (wave_row_dots6), then one lane per sample
@@ -2175,10 +2204,11 @@ __global__ __launch_bounds__(512) void corr_factor_kernel(const UgpmWin* __restr
 // diag(A^-1) = squared column norms of L^-1, 16 columns per workgroup; then dsc = state_std / sqrt(diag(A^-1)) (preint.h:1487-1489).
 // grid: (ceil(6S / 16), windows), block 256.  Dynamic LDS: (rows + 16) * 17 doubles for X, rows = 6 max_S.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void corr_diag_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin w = load_win(wins, blockIdx.y);
+  const WinPart wp = xcd_win_part();
+  const UgpmWin w = load_win(wins, wp.win);
   if (*w.status != 0 || !w.correlate) return;
   const int n = 6 * w.S;
-  const int jb = blockIdx.x, j0 = jb * 16;
+  const int jb = wp.part, j0 = jb * 16;
   if (j0 >= n) return;
   extern __shared__ double Xc[];
   __shared__ Solve16Lds sh;
@@ -2268,8 +2298,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const UgpmWin* __restrict__
 // Se3Integrator::get(t) (preint.h:1069-1153) + cov inflation of VelPreintegration::get (preint.h:1744-1757).
 // grid: (max n_infer, windows), block 256.
 __global__ __launch_bounds__(256) void infer_kernel(const UgpmWin* __restrict__ wins) {
-  const UgpmWin w = load_win(wins, blockIdx.y);
-  const int qi = blockIdx.x;
+  const WinPart wp = xcd_win_part();
+  const UgpmWin w = load_win(wins, wp.win);
+  const int qi = wp.part;
   if (qi >= w.n_infer) return;
   double* out = w.out + (size_t)qi * 83;
   if (*w.status != 0) {
