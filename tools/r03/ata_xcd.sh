@@ -1,4 +1,5 @@
 # J^T J launches: all tile groups of a window on one XCD (default) against the round-robin placement (-DGORIO_ATA_NO_XCD)
+# needs the comparison build first:  make -C go-rio_amd/csrc OUT=../../tools/variants/ata_noxcd.so EXTRA=-DGORIO_ATA_NO_XCD
 set -x
 mkdir -p gpurun_out/r03
 timeout -k 10 600 python -m pytest tests/test_ugpm_gpu.py tests/test_golden.py -m gpu -x -q > gpurun_out/r03/ata_tests.log 2>&1

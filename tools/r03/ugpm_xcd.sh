@@ -1,3 +1,5 @@
+# GP kernels launched as (parts, windows): window -> XCD placement (default) against the plain numbering
+# needs the comparison build first:  make -C go-rio_amd/csrc OUT=../../tools/variants/ugpm_noxcd.so EXTRA=-DGORIO_UGPM_XCD=0
 set -x
 mkdir -p gpurun_out/r03
 timeout -k 10 600 python -m pytest tests/test_ugpm_gpu.py tests/test_golden.py tests/test_host_cpp.py -m gpu -x -q > gpurun_out/r03/ux_tests.log 2>&1
