@@ -266,6 +266,26 @@ def test_batch_equals_single(gpu, gorio, pose_err):
     assert len({b["n_linearize"] for b in batch}) > 1  # the pairs really stop at different iterations
 
 
+@pytest.mark.parametrize("count", [24, 20])
+def test_ragged_batch_with_xcd_placement_equals_single(gpu, gorio, count):
+    """24 pairs (>= 16, a multiple of 8): linearize_kernel and the k-NN selection kernels renumber their workgroups so that a pair / a
+    cloud runs on one XCD (xcd_grid_pos, apd_device.h); 20 pairs: the plain numbering.  Clouds of very different sizes (workgroups past
+    the end of a small cloud leave at once), both optimisers: every pair must equal its own single align bit for bit, covariances too."""
+    pairs = [synth.scan_pair(300 + 211 * (q % 7), 2500 - 173 * (q % 11), seed=700 + q) for q in range(count)]
+    for opt in (0, 1):  # Gauss-Newton (the step fused into linearize_kernel), Levenberg-Marquardt
+        kw = dict(corr_dist_threshold=2.0, transformation_epsilon=0.05, optimizer=opt)
+        singles, covs = [], []
+        for pr in pairs[:: max(1, count // 6)]:
+            o = make(gorio, *pr[:4], **kw)
+            singles.append(o.align())
+            covs.append(o.getSourceCovariances())
+        objs = [make(gorio, *pr[:4], **kw) for pr in pairs]
+        batch = gorio.align_batch(objs)
+        for k, q in enumerate(range(0, count, max(1, count // 6))):
+            assert np.array_equal(singles[k]["T"], batch[q]["T"]) and singles[k]["n_linearize"] == batch[q]["n_linearize"]
+            assert np.array_equal(covs[k], objs[q].getSourceCovariances())
+
+
 def test_transform_source_and_fitness(gpu, gorio, oracle_apd):
     sx, sl, tx, tl, T = synth.scan_pair(800, 900, seed=12)
     g = make(gorio, sx, sl, tx, tl, corr_dist_threshold=2.0)
