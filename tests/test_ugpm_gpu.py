@@ -321,3 +321,18 @@ def test_chunked_mode_through_the_class_and_errors(gpu, gorio, ugpm_oracle):
         gorio.ugpm_preint_batch([win], infer_t=[[win["start_t"] - 1.0]], quantum=0.5)  # last stamp before start_t: no chunk
     good = gorio.ugpm_preint_batch([win], quantum=0.6)
     assert good[0][0]["dt"] == pytest.approx(1.5)
+
+
+@pytest.mark.parametrize("count", [24, 17])
+def test_window_batches_with_xcd_placement_equal_single_windows(gpu, gorio, count):
+    """24 windows (>= 16, a multiple of 8): the kernels launched as (parts, windows) and the J^T J launches renumber their workgroups so
+    that a window runs on one XCD (xcd_win_part, ata_kernel); 17 windows: the plain numbering.  Windows of different lengths (S from 56 to
+    86 states, different tile-group counts): every window of the batch must equal its own single-window call bit for bit."""
+    wins = [synth.imu_window(seed=900 + q, duration=0.8 + 0.1 * (q % 7)) for q in range(count)]
+    batch, dbatch = gorio.ugpm_preint_batch(wins, return_diag=True)
+    assert len({d["nb_state"] for d in dbatch}) >= 5
+    for q in range(0, count, 4):
+        single, dsingle = gorio.ugpm_preint_batch([wins[q]], return_diag=True)
+        assert dsingle[0]["iters_rot"] == dbatch[q]["iters_rot"] and dsingle[0]["iters_vel"] == dbatch[q]["iters_vel"]
+        for k in ("delta_R", "delta_p", "cov", "d_delta_R_d_bw", "d_delta_p_d_bw", "d_delta_p_d_bv", "d_delta_p_d_t", "d_delta_R_d_t"):
+            assert np.array_equal(single[0][0][k], batch[q][0][k]), (q, k)
