@@ -1930,6 +1930,71 @@ int gorio_prep_radius_outlier_mask(int device, const float* xyz, int n, int poin
   return GORIO_OK;
 }
 
+int gorio_prep_statistical_outlier_mask(int device, const float* xyz, int n, int point_stride_bytes, int mean_k, double stddev_mul, unsigned char* keep, int* n_kept,
+                                        float* mean_dist_out) {
+  if (!xyz || !keep || n <= 0 || point_stride_bytes < 12 || (point_stride_bytes % 4) || mean_k < 1 || mean_k > 31)
+    return prep_fail(GORIO_ERR_INVALID, "statistical_outlier_mask: bad arguments (mean_k must lie in [1, 31])");
+  if (n < mean_k + 1) return prep_fail(GORIO_ERR_INVALID, "statistical_outlier_mask: fewer points than mean_k + 1 (PCL then sums distances nearestKSearch never set)");
+  PrepCtx& c = g_prep;
+  if (!c.h || c.device != device) {
+    if (c.h) {
+      hipSetDevice(c.device);
+      hipFree(c.d_cnt); hipFree(c.d_offs); hipFree(c.d_adj);
+      gorio_apd_destroy(c.h);
+      c = PrepCtx();
+    }
+    const int rc = gorio_apd_create(&c.h, device);
+    if (rc) return prep_fail(rc, "statistical_outlier_mask: no usable HIP device (there is no CPU fallback)");
+    c.device = device;
+  }
+  gorio_apd* h = c.h;
+  h->params.search = GORIO_SEARCH_PRUNED;
+  int rc = gorio_apd_set_source(h, xyz, nullptr, n, point_stride_bytes);
+  if (rc) return prep_fail(rc, h->err);
+  {
+    std::vector<std::pair<gorio_apd*, DevCloud*>> one = {{h, h->src.get()}};
+    rc = run_index_build(h, one);
+    if (rc) return prep_fail(rc, h->err);
+  }
+  auto hip_fail = [&](const char* what, hipError_t e) { return prep_fail(GORIO_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
+  if ((size_t)n > c.pts_cap) {
+    hipFree(c.d_cnt); hipFree(c.d_offs);
+    c.d_cnt = nullptr; c.d_offs = nullptr;
+    c.pts_cap = 0;
+    hipError_t e = hipMalloc(&c.d_cnt, sizeof(int) * ((size_t)n + n / 8));
+    if (e == hipSuccess) e = hipMalloc(&c.d_offs, sizeof(long long) * ((size_t)n + n / 8));
+    if (e != hipSuccess) return hip_fail("hipMalloc", e);
+    c.pts_cap = (size_t)n + n / 8;
+  }
+  float* d_mean = reinterpret_cast<float*>(c.d_cnt);  // one 4-byte word per point, like the neighbour counts
+  sor_mean_distance_kernel<<<(roundup(n, 512) + 255) / 256, 256, 0, h->stream>>>(h->src->view(), mean_k + 1, d_mean);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail("sor_mean_distance_kernel", e);
+  std::vector<float> dist((size_t)n);
+  e = hipMemcpyAsync(dist.data(), d_mean, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return hip_fail("download", e);
+  // mean and standard deviation of the per-point values and the threshold, in PCL's order and types (statistical_outlier_removal.hpp:
+  // double sums over the float distances in point order, the n - 1 form of the variance); N numbers: done on the host
+  double sum = 0.0, sq_sum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    sum += dist[i];
+    sq_sum += dist[i] * dist[i];
+  }
+  const double mean = sum / static_cast<double>(n);
+  const double variance = (sq_sum - sum * sum / static_cast<double>(n)) / (static_cast<double>(n) - 1);
+  const double stddev = std::sqrt(variance);
+  const double threshold = mean + stddev_mul * stddev;
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    keep[i] = dist[i] <= threshold ? 1 : 0;  // negative_ = false: the inliers stay
+    kept += keep[i];
+    if (mean_dist_out) mean_dist_out[i] = dist[i];
+  }
+  if (n_kept) *n_kept = kept;
+  return GORIO_OK;
+}
+
 int gorio_prep_voxel_downsample(int device, const float* xyz, int n, int point_stride_bytes, double leaf, float* xyz_out, int out_stride_bytes, int out_capacity, int* n_out) {
   if (!xyz || !xyz_out || !n_out || n <= 0 || point_stride_bytes < 12 || (point_stride_bytes % 4) || out_stride_bytes < 12 || (out_stride_bytes % 4) || !(leaf > 0.0))
     return prep_fail(GORIO_ERR_INVALID, "voxel_downsample: bad arguments");

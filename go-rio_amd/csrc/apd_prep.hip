@@ -121,6 +121,72 @@ __global__ __launch_bounds__(256) void radius_count_kernel(CloudView cloud, floa
   if (p < n) cnt_out[si.orig[p]] = cnt;
 }
 
+
+// pcl::StatisticalOutlierRemoval, first half (PCL 1.10 filters/impl/statistical_outlier_removal.hpp, as preprocessing_nodelet_ntu.cpp:
+// 153-162 configures it -- the nodelet's DEFAULT outlier filter, mean_k 20 / 30): for every point the mean of the distances to its
+// mean_k nearest neighbours, the point itself (the first of the mean_k + 1 results of nearestKSearch) left out.  The k = mean_k + 1
+// smallest float squared distances are kept as in knn_kth_kernel -- an ascending register list, a candidate enters by
+// D[t] = med3(D[t-1], c, D[t]) -- with ONE list length for every k <= 32: the 32 - k slots below the list proper hold -inf, which no
+// candidate moves, so D[31] is the k-th smallest throughout.  The sum runs over the sorted distances 1 .. k-1 in double, on double
+// square roots of the float values, and is divided by mean_k and rounded to float as PCL does.
+// grid: ceil(n_spad / 256), block 256; mean_out[] by ORIGINAL index.
+__global__ __launch_bounds__(256) void sor_mean_distance_kernel(CloudView cloud, int k, float* __restrict__ mean_out) {
+  constexpr int K = 32;
+  const SearchIndex& si = cloud.idx;
+  const int n = si.n;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int pq = p < n ? p : n - 1;
+  const float qx = si.sx[pq], qy = si.sy[pq], qz = si.sz[pq];
+  const float qlo[3] = {wave_min(qx), wave_min(qy), wave_min(qz)};
+  const float qhi[3] = {wave_max(qx), wave_max(qy), wave_max(qz)};
+  const scalar_fp tx = as_scalar(si.sx);
+  const scalar_fp ty = as_scalar(si.sy);
+  const scalar_fp tz = as_scalar(si.sz);
+  const float4* __restrict__ tb4 = reinterpret_cast<const float4*>(si.tbox);
+  const int ng = (si.n_tiles + 63) / 64;
+  const int g0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) / 32 / 64;  // the group of this wave's own tiles: visited first, it tightens the bounds
+  float D[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) D[t] = t < K - k ? -INFINITY : INFINITY;
+  for (int v = 0; v < 2 * ng; ++v) {
+    const int off = (v + 1) >> 1;
+    const int g = (v & 1) ? g0 - off : g0 + off;
+    if (g < 0 || g >= ng) continue;
+    const int tl = g * 64 + lane;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+    if (tl < si.n_tiles) {
+      lo = tb4[2 * (size_t)tl];
+      hi = tb4[2 * (size_t)tl + 1];
+    }
+    const float wb = wave_max(D[K - 1]);
+    unsigned long long mask = __ballot(box_box_bound(qlo, qhi, lo, hi) < wb);  // strictly below: an equal distance changes no distance list
+    while (mask) {
+      const int tlane = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float bx[8] = {lane_f(lo.x, tlane), lane_f(lo.y, tlane), lane_f(lo.z, tlane), 0.f, lane_f(hi.x, tlane), lane_f(hi.y, tlane), lane_f(hi.z, tlane), 0.f};
+      if (__ballot(box_bound(qx, qy, qz, bx) < D[K - 1]) == 0) continue;
+      const int j0 = (g * 64 + tlane) * 32;
+#pragma unroll 2
+      for (int u = 0; u < 32; ++u) {
+        const float c = sqdist3(qx, qy, qz, tx[j0 + u], ty[j0 + u], tz[j0 + u]);  // padding points sit at 1e30: c = inf
+        if (__ballot(c < D[K - 1]) == 0) continue;
+#pragma unroll
+        for (int t = K - 1; t > 0; --t) D[t] = __builtin_amdgcn_fmed3f(D[t - 1], c, D[t]);
+        D[0] = __builtin_amdgcn_fmed3f(D[0], c, -INFINITY);
+      }
+    }
+  }
+  if (p < n) {
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 1; t < K; ++t)  // slot K - k is the query itself (distance 0, or the nearest of its duplicates)
+      if (t > K - k) sum += sqrt((double)D[t]);
+    mean_out[si.orig[p]] = (float)(sum / (double)(k - 1));
+  }
+}
+
 }  // namespace gorio
 
 // ----------------------------------------------------------------------------------------------- REVE Doppler ego-velocity

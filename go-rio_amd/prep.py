@@ -5,7 +5,7 @@ import numpy as np
 
 from .apd import GorioError, load_library
 
-PREP_SYMBOLS = ["gorio_prep_dbscan_labels", "gorio_prep_radius_outlier_mask", "gorio_prep_voxel_downsample", "gorio_prep_last_error", "gorio_prep_reve_default_config", "gorio_prep_reve_ransac_iterations", "gorio_prep_ego_velocity"]
+PREP_SYMBOLS = ["gorio_prep_dbscan_labels", "gorio_prep_radius_outlier_mask", "gorio_prep_statistical_outlier_mask", "gorio_prep_voxel_downsample", "gorio_prep_last_error", "gorio_prep_reve_default_config", "gorio_prep_reve_ransac_iterations", "gorio_prep_ego_velocity"]
 
 
 def dbscan_labels(xyz, eps=0.9, core_min_pts=10, min_cluster_size=20, max_cluster_size=25000, device=0):
@@ -57,6 +57,26 @@ def radius_outlier_mask(xyz, radius=2.0, min_neighbors=2, device=0):
         msg = lib.gorio_prep_last_error()
         raise GorioError(rc, msg.decode() if msg else "")
     return keep.astype(bool)
+
+
+def statistical_outlier_mask(xyz, mean_k=20, stddev_mul=1.0, device=0, return_distances=False):
+    """pcl::StatisticalOutlierRemoval (preprocessing_nodelet_ntu.cpp:153-162, the nodelet's default filter): boolean keep mask [n]
+    (and, on request, the per-point mean neighbour distances)."""
+    lib = load_library()
+    lib.gorio_prep_last_error.restype = C.c_char_p
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    if xyz.ndim != 2 or xyz.shape[1] != 3:
+        raise ValueError("xyz must be [n, 3]")
+    n = xyz.shape[0]
+    keep = np.zeros(n, np.uint8)
+    dist = np.zeros(n, np.float32)
+    nk = C.c_int(0)
+    rc = lib.gorio_prep_statistical_outlier_mask(int(device), C.c_void_p(xyz.__array_interface__["data"][0]), n, 12, int(mean_k), C.c_double(stddev_mul),
+                                                 C.c_void_p(keep.__array_interface__["data"][0]), C.byref(nk), C.c_void_p(dist.__array_interface__["data"][0]))
+    if rc < 0:
+        msg = lib.gorio_prep_last_error()
+        raise GorioError(rc, msg.decode() if msg else "")
+    return (keep.astype(bool), dist) if return_distances else keep.astype(bool)
 
 
 class ReveConfig(C.Structure):

@@ -37,6 +37,18 @@ int gorio_prep_dbscan_labels(int device, const float* xyz, int n, int point_stri
 int gorio_prep_radius_outlier_mask(int device, const float* xyz, int n, int point_stride_bytes, double radius, int min_neighbors, unsigned char* keep, int* n_kept);
 
 /*
+ * pcl::StatisticalOutlierRemoval as preprocessing_nodelet_ntu.cpp:153-162, 626-634 configures it -- the nodelet's DEFAULT outlier filter
+ * (statistical_mean_k 20, statistical_stddev 1.0; the launch files carry 30 / 1.2 beside their RADIUS choice): for every point the mean
+ * distance to its mean_k nearest neighbours (PCL 1.10 filters/impl/statistical_outlier_removal.hpp: nearestKSearch with mean_k + 1, the
+ * first result -- the point itself -- left out, double sum of the square roots of the float squared distances, divided by mean_k, kept
+ * as float), then keep[i] = 1 when that value is at most mean + stddev_mul * stddev over all points (double sums in point order,
+ * variance with n - 1).  mean_k in [1, 31], n > mean_k.  mean_dist_out (n floats, may be NULL) receives the per-point values.
+ * PCL / FLANN are not in the image: the restatement this is tested against follows the source as recalled (parity unpinned).
+ */
+int gorio_prep_statistical_outlier_mask(int device, const float* xyz, int n, int point_stride_bytes, int mean_k, double stddev_mul, unsigned char* keep, int* n_kept,
+                                        float* mean_dist_out);
+
+/*
  * pcl::VoxelGrid as the preprocessing nodelet applies it to every scan (preprocessing_nodelet_ntu.cpp:137-139, 608-622; launch files:
  * downsample_method VOXELGRID, downsample_resolution 0.1): one output point per occupied voxel = the centroid of its points, output
  * ordered by voxel index as PCL's sorted index vector yields it.  Only the coordinates are produced: they are all the hot path reads

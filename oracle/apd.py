@@ -235,6 +235,18 @@ def radius_outlier_mask(xyz, radius=2.0, min_pts=2):
     return keep[:n].astype(bool)
 
 
+def statistical_outlier_mask(xyz, mean_k=20, stddev_mul=1.0):
+    """pcl::StatisticalOutlierRemoval (preprocessing_nodelet_ntu.cpp:153-162): (boolean keep mask, per-point mean neighbour distances)."""
+    xyz = _f32(xyz)
+    n = xyz.shape[0]
+    keep = np.zeros(max(n, 1), np.uint8)
+    dist = np.zeros(max(n, 1), np.float32)
+    rc = lib().apdo_statistical_outlier_mask(_p(xyz, C.c_float), n, int(mean_k), C.c_double(stddev_mul), _p(keep, C.c_ubyte), _p(dist, C.c_float))
+    if rc < 0:
+        raise ValueError("statistical_outlier_mask: n must exceed mean_k (and mean_k <= 63)")
+    return keep[:n].astype(bool), dist[:n].copy()
+
+
 class ReveConfig(C.Structure):
     """apdo_reve_config == RadarEgoVelocityEstimatorConfig (radar_ego_velocity_estimator.h:30-60), the fields the estimator reads."""
     _fields_ = [(k, C.c_float) for k in (

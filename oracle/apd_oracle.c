@@ -1137,6 +1137,57 @@ int apdo_radius_outlier_mask(const float* xyz, int n, double radius, int min_pts
   return kept;
 }
 
+/*
+ * pcl::StatisticalOutlierRemoval as the preprocessing nodelet uses it by default (PREP:153-162, 626-634; statistical_mean_k 20,
+ * statistical_stddev 1.0 -- the launch files carry 30 / 1.2).  PCL 1.10 filters/impl/statistical_outlier_removal.hpp, restated from
+ * memory of that source ("parity unpinned": PCL is not under /root/reference): for every point nearestKSearch(point, mean_k + 1) on
+ * the cloud itself (sorted float squared distances, the first being the query at 0), dist_sum (double) += sqrt(nn_dists[k]) for
+ * k = 1 .. mean_k with the global-namespace sqrt, i.e. in double, distances[i] = (float)(dist_sum / mean_k); then over all points in
+ * index order: sum += d, sq_sum += d * d (double, d float), mean = sum / n, variance = (sq_sum - sum * sum / n) / (n - 1),
+ * threshold = mean + stddev_mul * sqrt(variance); a point stays when distances[i] <= threshold.
+ * Restated without the tree: the mean_k + 1 smallest float squared distances of every point by a bounded insertion.
+ * keep_out[n], dist_out[n] (may be NULL); returns the number of points kept, -1 when n <= mean_k or mean_k > 63.
+ */
+int apdo_statistical_outlier_mask(const float* xyz, int n, int mean_k, double stddev_mul, unsigned char* keep_out, float* dist_out) {
+  const int k = mean_k + 1;
+  if (mean_k < 1 || mean_k > 63 || n < k) return -1;
+  float* dist = (float*)malloc(sizeof(float) * (size_t)n);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    float best[64];
+    int m = 0;
+    for (int j = 0; j < n; ++j) {
+      const float d = sqdist3f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]);
+      if (m == k && !(d < best[k - 1])) continue;
+      int t = m < k ? m++ : k - 1;
+      while (t > 0 && best[t - 1] > d) {
+        best[t] = best[t - 1];
+        --t;
+      }
+      best[t] = d;
+    }
+    double dist_sum = 0.0;
+    for (int t = 1; t < k; ++t) dist_sum += sqrt((double)best[t]);
+    dist[i] = (float)(dist_sum / mean_k);
+  }
+  double sum = 0.0, sq_sum = 0.0;
+  for (int i = 0; i < n; ++i) {
+    sum += dist[i];
+    sq_sum += dist[i] * dist[i];
+  }
+  const double mean = sum / (double)n;
+  const double variance = (sq_sum - sum * sum / (double)n) / ((double)n - 1);
+  const double threshold = mean + stddev_mul * sqrt(variance);
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    keep_out[i] = dist[i] <= threshold ? 1 : 0;
+    kept += keep_out[i];
+    if (dist_out) dist_out[i] = dist[i];
+  }
+  free(dist);
+  return kept;
+}
+
 /* ------------------------------------------------------------------------------------------------ preprocessing: DBSCAN cluster labels
  *
  * PREP = /root/reference/4DRadarSLAM/apps/preprocessing_nodelet_ntu.cpp, DBS = /root/reference/4DRadarSLAM/include/dbscan/DBSCAN_simple.h.

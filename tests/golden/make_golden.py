@@ -48,6 +48,7 @@ def main():
     json.dump(out, open(os.path.join(HERE, "ugpm_c2_windows.json"), "w"), indent=1)
     make_prep_golden(synth, apd, ugpm)
     make_chunked_golden(synth, ugpm)
+    make_sor_golden(synth, apd)
     print("golden fixtures written to", HERE)
 
 
@@ -64,6 +65,14 @@ def make_chunked_golden(synth, ugpm):
     out = dict(quantum=quantum, diag={k: (float(v) if not isinstance(v, int) else v) for k, v in d.items()},
                records=[{k: np.asarray(v).tolist() for k, v in m.items()} for m in res[0]])
     json.dump(out, open(os.path.join(HERE, "ugpm_chunked.json"), "w"), indent=1)
+
+
+def make_sor_golden(synth, apd):
+    """pcl::StatisticalOutlierRemoval (the nodelet's default filter) on the scan of prep_inputs(): mask and per-point mean distances."""
+    d = prep_inputs(synth)
+    keep, dist = apd.statistical_outlier_mask(d["scan"], 20, 1.0)
+    keep30, _ = apd.statistical_outlier_mask(d["scan"], 30, 1.2)
+    np.savez_compressed(os.path.join(HERE, "prep_sor.npz"), keep_20_10=keep, dist_20=dist, keep_30_12=keep30)
 
 
 def prep_inputs(synth):
@@ -114,6 +123,14 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "chunked":  #
 
     oracle.build()
     make_chunked_golden(importlib.import_module("go-rio_amd.synth"), _u)
+    sys.exit(0)
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sor":  # only the statistical-outlier fixture
+    import oracle
+    from oracle import apd as _a
+
+    oracle.build()
+    make_sor_golden(importlib.import_module("go-rio_amd.synth"), _a)
     sys.exit(0)
 
 if __name__ == "__main__":

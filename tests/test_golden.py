@@ -155,3 +155,21 @@ def test_gpu_matches_prep_submap_lpm_golden(gpu, gorio):
         rot = np.linalg.norm(Rot.from_matrix(g["lpm_delta_R"][k].T @ m["delta_R"]).as_rotvec())
         assert rot < 1e-10 and np.linalg.norm(m["delta_p"] - g["lpm_delta_p"][k]) < 1e-10
         assert np.allclose(m["cov"], g["lpm_cov"][k], rtol=1e-8, atol=1e-9 * np.abs(g["lpm_cov"][k]).max())
+
+
+def test_oracle_reproduces_sor_golden(oracle_apd):
+    _, d = _prep_golden()
+    g = np.load(os.path.join(GOLD, "prep_sor.npz"))
+    keep, dist = oracle_apd.statistical_outlier_mask(d["scan"], 20, 1.0)
+    assert np.array_equal(keep, g["keep_20_10"]) and np.array_equal(dist, g["dist_20"])
+    assert np.array_equal(oracle_apd.statistical_outlier_mask(d["scan"], 30, 1.2)[0], g["keep_30_12"])
+
+
+@pytest.mark.gpu
+def test_gpu_matches_sor_golden(gpu, gorio):
+    _, d = _prep_golden()
+    g = np.load(os.path.join(GOLD, "prep_sor.npz"))
+    keep, dist = gorio.prep.statistical_outlier_mask(d["scan"], 20, 1.0, return_distances=True)
+    assert np.array_equal(keep, g["keep_20_10"]) and np.array_equal(dist, g["dist_20"])
+    assert np.array_equal(gorio.prep.statistical_outlier_mask(d["scan"], 30, 1.2), g["keep_30_12"])
+

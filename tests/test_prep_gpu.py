@@ -217,6 +217,61 @@ def test_radius_outlier_mask_counts_duplicates_and_isolated_points(gpu, gorio, o
     assert keep[:3].all() and not keep[3] and not keep[4] and not keep[5]  # three coincident points count each other; a pair is one short
 
 
+# ------------------------------------------------------------------------------------------------ statistical outlier removal (the nodelet's default filter)
+
+def test_oracle_statistical_outlier_mask_against_kdtree(oracle_apd):
+    """CPU: the restatement against an independent computation (scipy cKDTree in double on the float coordinates): per-point mean
+    neighbour distances to 1e-5, and the same mask wherever a point is not within 1e-5 of the threshold."""
+    from scipy.spatial import cKDTree
+
+    xyz, _ = synth.radar_scan(6000, seed=synth.BASE_SEED + 65)
+    tree = cKDTree(xyz.astype(np.float64))
+    for mean_k, mul in ((20, 1.0), (30, 1.2), (5, 0.5)):
+        keep, dist = oracle_apd.statistical_outlier_mask(xyz, mean_k, mul)
+        dd, _ = tree.query(xyz.astype(np.float64), k=mean_k + 1)
+        ref = dd[:, 1:].mean(axis=1)
+        assert np.abs(ref - dist).max() < 1e-5 * max(1.0, ref.max())
+        thr = ref.mean() + mul * ref.std(ddof=1)
+        sure = np.abs(ref - thr) > 1e-5 * max(1.0, thr)
+        assert sure.mean() > 0.99 and np.array_equal(keep[sure], (ref <= thr)[sure])
+        assert 0 < keep.sum() < len(xyz)
+    with pytest.raises(ValueError):
+        oracle_apd.statistical_outlier_mask(xyz[:10], 20, 1.0)  # fewer points than mean_k + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mean_k,mul", [(20, 1.0), (30, 1.2), (1, 0.0), (31, 2.0)])
+def test_statistical_outlier_mask_matches_oracle(gpu, gorio, oracle_apd, mean_k, mul):
+    """pcl::StatisticalOutlierRemoval with the nodelet's defaults (20, 1.0), the launch files' values (30, 1.2) and the ends of the
+    supported range: per-point mean neighbour distances and the mask equal the CPU restatement exactly (the same float squared
+    distances, sorted, double square roots summed in the same order, the statistics in PCL's order on the host)."""
+    for seed, n in ((66, 16384), (67, 3000), (68, 257)):
+        xyz, _ = synth.radar_scan(n, seed=synth.BASE_SEED + seed)
+        keep, dist = gorio.prep.statistical_outlier_mask(xyz, mean_k, mul, return_distances=True)
+        okeep, odist = oracle_apd.statistical_outlier_mask(xyz, mean_k, mul)
+        assert np.array_equal(dist, odist)
+        assert np.array_equal(keep, okeep)
+
+
+@pytest.mark.gpu
+def test_statistical_outlier_mask_duplicates_small_clouds_and_errors(gpu, gorio, oracle_apd):
+    rng = np.random.default_rng(9)
+    blob = rng.normal(0.0, 0.3, (60, 3)).astype(np.float32)
+    xyz = np.concatenate([blob, blob[:7], np.array([[30, 30, 3], [-40, 5, 0]], np.float32)])  # duplicates (zero distances beside the query's own) and two far points
+    keep, dist = gorio.prep.statistical_outlier_mask(xyz, 8, 1.0, return_distances=True)
+    okeep, odist = oracle_apd.statistical_outlier_mask(xyz, 8, 1.0)
+    assert np.array_equal(dist, odist) and np.array_equal(keep, okeep)
+    assert not keep[-1] and not keep[-2] and keep[:60].all()
+    tiny = xyz[:9]
+    k2, d2 = gorio.prep.statistical_outlier_mask(tiny, 8, 1.0, return_distances=True)  # n = mean_k + 1: every other point is a neighbour
+    o2, od2 = oracle_apd.statistical_outlier_mask(tiny, 8, 1.0)
+    assert np.array_equal(d2, od2) and np.array_equal(k2, o2)
+    with pytest.raises(gorio.GorioError):
+        gorio.prep.statistical_outlier_mask(tiny, 9, 1.0)  # fewer points than mean_k + 1
+    with pytest.raises(gorio.GorioError):
+        gorio.prep.statistical_outlier_mask(xyz, 32, 1.0)  # mean_k + 1 > 32 list slots
+
+
 # ------------------------------------------------------------------------------------------------ voxel-grid downsampling
 
 @pytest.mark.gpu
