@@ -77,6 +77,7 @@ struct gorio_apd {
   unsigned int* nn_work = nullptr;  // PairDesc::nn_work / nn_plan (measured work of the query waves, plan of the next searches)
   unsigned int* nn_plan = nullptr;
   int nn_wcap = 0;
+  int align_budget = 0;    // loop iterations the previous batch led by this handle needed (0 = none yet): enqueued before the first look at the done flags
   int* corr = nullptr;
   float* sqd = nullptr;
   double* omega6 = nullptr;
@@ -921,7 +922,10 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     return GORIO_OK;
   }
   int launched = 0;
-  int chunk_iters = 4;
+  // Iterations between looks at the done flags (a look drains the stream): 4, 8, 16, 16, ... for the first batch of a handle; later
+  // batches first enqueue as many iterations as the previous batch needed -- on like data that look is the only one.  A finished pair's
+  // kernels return at once, so the schedule of the looks never changes a result.
+  int chunk_iters = lead->align_budget > 0 ? lead->align_budget : 4;
   const bool fuse_gn = lead->params.optimizer != GORIO_OPT_LEVENBERG_MARQUARDT && lead->fuse_step;
   const int max_it = lead->params.max_iterations;
   while (launched < max_it) {
@@ -940,7 +944,7 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
       }
     }
     launched += todo_it;
-    chunk_iters = std::min(16, chunk_iters * 2);  // every look at the done flags drains the stream: 4, 8, 16, 16, ... iterations between looks
+    chunk_iters = launched == todo_it && lead->align_budget > 0 ? 4 : std::min(16, chunk_iters * 2);  // after a budgeted first chunk: 4, 8, 16, ...
     HIP_TRY(lead, hipGetLastError());
     gather_states_kernel<<<count, 64, 0, lead->stream>>>(lead->d_desc, lead->d_states_batch);
     HIP_TRY(lead, hipMemcpyAsync(states.data(), lead->d_states_batch, sizeof(PairState) * count, hipMemcpyDeviceToHost, lead->stream));
@@ -948,6 +952,11 @@ int align_impl(gorio_apd** hs, int count, const float* guesses, float* T_out, do
     bool all_done = true;
     for (int q = 0; q < count; ++q) all_done = all_done && states[q].done;
     if (all_done) break;
+  }
+  {
+    int need = 1;  // loop iterations the slowest pair used = its linearisations
+    for (int q = 0; q < count; ++q) need = std::max(need, states[q].n_linearize);
+    lead->align_budget = std::min(need, max_it);
   }
   for (int q = 0; q < count; ++q) {
     const PairState& s = states[q];
