@@ -47,6 +47,8 @@ struct Ctx {  // per-thread, per-device cached buffers
   int* d_ints = nullptr;  // per window: kWinInts ints (lmi[16], status)
   int lm_budget[2] = {0, 0};  // iterations the two fits of the PREVIOUS batch needed: that many are enqueued before the first look at the done flags
   double* d_diag = nullptr;
+  double* pin_in = nullptr;  // pinned staging of the batch's input arrays (the H2D copy is then a DMA the call does not wait for)
+  size_t pin_in_cap = 0;
   // opt.type = LPM windows (ugpm_lpm_out.hip)
   double* lpm_ws = nullptr;
   size_t lpm_ws_cap = 0;
@@ -254,6 +256,7 @@ static int preint_batch_flat(const gorio_ugpm_window* windows, int n_windows, go
     if (c.ev_jac) hipEventDestroy(c.ev_jac);
     if (c.ev_corr) hipEventDestroy(c.ev_corr);
     hipFree(c.ws); hipFree(c.d_wins); hipFree(c.d_ints); hipFree(c.d_diag); hipFree(c.lpm_ws); hipFree(c.lpm_ints); hipFree(c.d_lpm_wins);
+    if (c.pin_in) hipHostFree(c.pin_in);
     c = Ctx();
     c.device = device;
     bool made = false;
@@ -362,12 +365,18 @@ static int preint_batch_flat(const gorio_ugpm_window* windows, int n_windows, go
 
   // ---- carve the workspace, stage the inputs
   std::vector<UgpmWin> dw(n_windows);
-  std::vector<double> stage_in;
   std::vector<int> ints(kWinInts * (size_t)n_windows, 0);
   double* in_region = c.ws;
   double* out_region = c.ws + total_in;
   double* base = out_region + (total_out + 31) / 32 * 32;
-  stage_in.assign(total_in, 0.0);
+  if (total_in > c.pin_in_cap) {
+    if (c.pin_in) hipHostFree(c.pin_in);
+    c.pin_in = nullptr;
+    c.pin_in_cap = 0;
+    UHIP(hipHostMalloc(reinterpret_cast<void**>(&c.pin_in), sizeof(double) * (total_in + total_in / 4 + 64), hipHostMallocDefault));
+    c.pin_in_cap = total_in + total_in / 4 + 64;
+  }
+  double* const stage_in = c.pin_in;  // every use of it ends before this call returns (the call ends with a stream synchronisation)
   size_t in_off = 0, out_off = 0;
   std::vector<size_t> out_offs(n_windows, 0);
   for (int i = 0; i < n_windows; ++i) {
@@ -396,7 +405,9 @@ static int preint_batch_flat(const gorio_ugpm_window* windows, int n_windows, go
     for (int a = 0; a < 3; ++a) { u.gyr_bias[a] = w.gyr_bias[a]; u.vel_bias[a] = w.vel_bias[a]; }
     u.vel_bias_std = w.vel_bias_std; u.gyr_bias_std = w.gyr_bias_std;
     base += h.ws_doubles;
-    double* s = stage_in.data() + in_off;
+    double* s = stage_in + in_off;
+    const size_t padded = (input_doubles(w, h) + 3) / 4 * 4;
+    for (size_t k = padded - 4; k < padded; ++k) s[k] = 0.0;  // the padding of this window's slot (filled below up to input_doubles)
     for (size_t k = 0; k < G; ++k) s[k] = w.gyr_t[h.g0 + k];
     s += G;
     for (int a = 0; a < 3; ++a)
@@ -412,7 +423,7 @@ static int preint_batch_flat(const gorio_ugpm_window* windows, int n_windows, go
     for (size_t k = 0; k < S; ++k) s[k] = h.state_t[k];
     in_off += (input_doubles(w, h) + 3) / 4 * 4;
   }
-  if (total_in) UHIP(hipMemcpyAsync(in_region, stage_in.data(), sizeof(double) * total_in, hipMemcpyHostToDevice, c.stream));
+  if (total_in) UHIP(hipMemcpyAsync(in_region, stage_in, sizeof(double) * total_in, hipMemcpyHostToDevice, c.stream));
   UHIP(hipMemcpyAsync(c.d_wins, dw.data(), sizeof(UgpmWin) * n_windows, hipMemcpyHostToDevice, c.stream));
   UHIP(hipMemcpyAsync(c.d_ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice, c.stream));
   UHIP(hipMemsetAsync(c.d_diag, 0, sizeof(double) * 4 * n_windows, c.stream));  // windows no solver touches report zero iterations
