@@ -45,4 +45,27 @@ while time.time() - t0 < budget:
         assert rot < 1e-4 and np.linalg.norm(a["delta_p"] - b["delta_p"]) < 1e-4 and diag[q]["iters_rot"] == do["iters_rot"] and diag[q]["iters_vel"] == do["iters_vel"], (count, q, rot, diag[q], do)
         assert np.allclose(a["cov"], b["cov"], rtol=1e-3, atol=1e-3 * np.abs(b["cov"]).max())
         n_windows += 1
+# chunked requests, LPM output type, preprocessing filters: a few random cases each
+n_extra = 0
+t1 = time.time()
+while time.time() - t1 < min(40.0, 0.25 * budget):
+    w = synth.imu_window(seed=int(rng.integers(1, 1 << 30)), duration=float(rng.uniform(1.0, 2.2)))
+    quantum = float(rng.uniform(0.35, 0.9))
+    q = sorted(float(w["start_t"] + rng.uniform(0.05, 1.0) * (w["end_t"] - w["start_t"])) for _ in range(int(rng.integers(1, 4)))) + [w["end_t"]]
+    typ = int(rng.integers(0, 2))
+    ro, _ = ougpm.preintegrate_chunked(w, quantum, infer_t=q, type=typ)
+    rg = gorio.ugpm_preint_batch([w], infer_t=[q], quantum=quantum, type=typ)
+    for a, b in zip(rg[0], ro[0]):
+        rot = np.linalg.norm(Rot.from_matrix(b["delta_R"].T @ a["delta_R"]).as_rotvec())
+        assert rot < 1e-4 and np.linalg.norm(a["delta_p"] - b["delta_p"]) < 1e-4 and abs(a["dt"] - b["dt"]) < 1e-12, ("chunked", typ, quantum, rot)
+    xyz, _ = synth.radar_scan(int(rng.integers(200, 9000)), seed=int(rng.integers(1, 1 << 30)))
+    mk = int(rng.integers(1, 32))
+    if len(xyz) > mk:
+        keep, dist = gorio.prep.statistical_outlier_mask(xyz, mk, float(rng.uniform(0.0, 2.0)), return_distances=True)
+        ok, od = oapd.statistical_outlier_mask(xyz, mk, 1.0)
+        assert np.array_equal(dist, od), ("sor", len(xyz), mk)
+    r, mn = float(rng.uniform(0.5, 4.0)), int(rng.integers(1, 8))
+    assert np.array_equal(gorio.prep.radius_outlier_mask(xyz, r, mn), oapd.radius_outlier_mask(xyz, r, mn)), ("radius", len(xyz), r, mn)
+    n_extra += 1
+print("extra cases (chunked request + statistical + radius filter each):", n_extra)
 print("soak ok:", n_batches, "registration batches,", n_pairs, "pairs and", n_windows, "windows checked against the oracle in", round(time.time() - t0), "s")
