@@ -199,12 +199,12 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const IndexJob* __re
 // every segment by that coordinate, payload permutation.  Padding points (1e30) are the largest on every axis and therefore stay
 // at the tail of the chunk.  grid: (chunks over max n_spad, jobs), block 1024.
 // Chunk size (a multiple of 1024, at most 4096: the index inside a chunk takes 12 key bits) by the clouds of the call: 2048 points when
-// every cloud named in the call has at most kKdSmallCloud points, 4096 otherwise.  Measured in round 3: 16 k-point scans against each other
+// every cloud named in the call has at most kKdSmallCloud points (scans, and local maps of the C3 size), 4096 otherwise.  Measured in round 3: 16 k-point scans against each other
 // build faster with the smaller chunk (0.71 -> 0.60 ms per C4 batch: 512-thread workgroups, one sort level less) AND search faster (20
 // searches 1.99 -> 1.90 ms, k-NN 1.66 -> 1.59 ms, a lone 5 k x 5 k align 0.95 -> 0.79 ms); scans that meet a big map search it faster
 // when THEY are ordered with 4096-point chunks too (64 scans x 1 M-point map: 20 searches 10.2 vs 10.9 ms), and the map's own tiles are
 // worse with small chunks (11.2 ms with 1024).
-constexpr int kKdSmallCloud = 65536;
+constexpr int kKdSmallCloud = 131072;  // (65536 until the end of round 3: a 100 k-point local map is better off with 2048-point chunks too -- C3 step 2.72 -> 2.55 ms)
 template <int kKdChunk>
 __global__ __launch_bounds__(kKdChunk / 4) void kd_refine_kernel(const IndexJob* __restrict__ jobs) {
   constexpr int kKdThreads = kKdChunk / 4;  // four points, two compare-exchange pairs per thread and stage
